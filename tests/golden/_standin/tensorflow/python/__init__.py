@@ -1,0 +1,1 @@
+"""package marker for the stand-in (see ../__init__.py)"""
