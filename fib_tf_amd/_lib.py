@@ -1,0 +1,227 @@
+"""ctypes binding of libfibhip.so (include/fibhip.h) — the only door between the Python API and
+the HIP kernels.  There is deliberately no fallback: if the shared library is missing or no HIP
+device is present, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, 'libfibhip.so')
+SRC = os.path.join(HERE, 'csrc', 'fibhip.hip')
+HDR = os.path.join(ROOT, 'include', 'fibhip.h')
+
+FENTON4V, BR, COURT = 0, 1, 2
+CHEBY, SKIP, CHRONIC, FAST, ALLVARS = 1, 2, 4, 8, 16
+
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
+               '-Wall', '-Wno-unused-value', '-Wno-unused-result']
+
+
+class FibhipError(RuntimeError):
+    pass
+
+
+class Desc(C.Structure):
+    _fields_ = [('struct_size', C.c_int), ('model', C.c_int), ('height', C.c_int), ('width', C.c_int),
+                ('dt', C.c_double), ('diff', C.c_double), ('flags', C.c_uint), ('device', C.c_int),
+                ('steps_per_tick', C.c_int), ('global_height', C.c_int), ('row_offset', C.c_int),
+                ('ghost_top', C.c_int), ('ghost_bottom', C.c_int), ('stream', C.c_void_p),
+                ('ext_slab', C.c_void_p * 2)]
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_h = C.c_void_p
+
+# name -> (argtypes, restype): every symbol include/fibhip.h declares
+SYMBOLS = {
+    'fibhip_nvar': ([C.c_int], C.c_int),
+    'fibhip_default_steps_per_tick': ([C.c_int], C.c_int),
+    'fibhip_abi_version': ([], C.c_int),
+    'fibhip_device_count': ([], C.c_int),
+    'fibhip_create': ([C.POINTER(Desc), C.POINTER(_h)], C.c_int),
+    'fibhip_destroy': ([_h], C.c_int),
+    'fibhip_set_phase': ([_h, _fp], C.c_int),
+    'fibhip_set_state': ([_h, C.c_int, _fp], C.c_int),
+    'fibhip_get_state': ([_h, C.c_int, _fp], C.c_int),
+    'fibhip_set_consts': ([_h, _fp, C.c_int], C.c_int),
+    'fibhip_step': ([_h, C.c_int], C.c_int),
+    'fibhip_step_slow': ([_h], C.c_int),
+    'fibhip_pace': ([_h, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float], C.c_int),
+    'fibhip_probe': ([_h, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'fibhip_sync': ([_h], C.c_int),
+    'fibhip_time_steps': ([_h, C.c_int, _fp, _ip], C.c_int),
+    'fibhip_step_edges': ([_h], C.c_int),
+    'fibhip_step_interior': ([_h], C.c_int),
+    'fibhip_step_commit': ([_h], C.c_int),
+    'fibhip_state_ptr': ([_h, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    'fibhip_next_ptr': ([_h, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    'fibhip_halo_vars': ([_h], C.c_int),
+    'fibhip_unit_op': ([C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_double, C.c_int, _fp],
+                       C.c_int),
+    'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
+    'fibhip_last_error': ([], C.c_char_p),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """compile csrc/fibhip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
+    deps = [SRC, HDR, os.path.join(HERE, 'csrc', 'kernels.hpp'), os.path.join(HERE, 'csrc', 'models.hpp')]
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        return SO
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + HIPCC_FLAGS + [SRC, '-o', SO]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise FibhipError('libfibhip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"`); '
+                              'fib_tf_amd has no CPU fallback')
+        L = C.CDLL(SO)
+        for name, (args, res) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.argtypes, fn.restype = args, res
+        if L.fibhip_abi_version() != 1:
+            raise FibhipError('libfibhip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise FibhipError(lib().fibhip_last_error().decode('utf-8', 'replace'))
+    return rc
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def unit_op(op, a, b=None, c=None, phi=None, dt=0.0, fast=False, device=0):
+    a = _f32(a)
+    H, W = a.shape
+    b = None if b is None else _f32(b)
+    c = None if c is None else _f32(c)
+    phi = None if phi is None else _f32(phi)
+    out = np.empty_like(a)
+    check(lib().fibhip_unit_op(device, op, H, W, _ptr(a), _ptr(b), _ptr(c), _ptr(phi), float(dt), int(fast),
+                               _ptr(out)))
+    return out
+
+
+class Stepper:
+    """One fibhip handle: a grid (or a row block of it) resident on one MI355X."""
+
+    def __init__(self, model, height, width, dt, diff, flags=0, device=0, steps_per_tick=0,
+                 global_height=0, row_offset=0, ghost_top=0, ghost_bottom=0, stream=None, ext_slabs=None):
+        L = lib()
+        d = Desc()
+        d.struct_size = C.sizeof(Desc)
+        d.model, d.height, d.width = model, height, width
+        d.dt, d.diff, d.flags, d.device = float(dt), float(diff), flags, device
+        d.steps_per_tick = steps_per_tick
+        d.global_height, d.row_offset = global_height, row_offset
+        d.ghost_top, d.ghost_bottom = ghost_top, ghost_bottom
+        d.stream = stream
+        if ext_slabs is not None:
+            d.ext_slab[0], d.ext_slab[1] = ext_slabs
+        self._h = _h()
+        self.nvar = check(L.fibhip_nvar(model))
+        self.height, self.width = height, width
+        self.steps_per_tick = steps_per_tick or check(L.fibhip_default_steps_per_tick(model))
+        check(L.fibhip_create(C.byref(d), C.byref(self._h)))
+        self._L = L
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._L.fibhip_destroy(self._h)
+            self._h = _h()
+
+    __del__ = close
+
+    def set_phase(self, phi):
+        if phi is None:
+            check(self._L.fibhip_set_phase(self._h, None))
+        else:
+            phi = _f32(phi)
+            assert phi.shape == (self.height, self.width)
+            check(self._L.fibhip_set_phase(self._h, _ptr(phi)))
+
+    def set_state(self, var, arr):
+        arr = _f32(arr)
+        want = (self.nvar, self.height, self.width) if var < 0 else (self.height, self.width)
+        assert arr.shape == want, (arr.shape, want)
+        check(self._L.fibhip_set_state(self._h, var, _ptr(arr)))
+
+    def get_state(self, var=-1):
+        shape = (self.nvar, self.height, self.width) if var < 0 else (self.height, self.width)
+        out = np.empty(shape, np.float32)
+        check(self._L.fibhip_get_state(self._h, var, _ptr(out)))
+        return out
+
+    def set_consts(self, tbl):
+        tbl = _f32(tbl).ravel()
+        check(self._L.fibhip_set_consts(self._h, _ptr(tbl), tbl.size))
+
+    def step(self, nticks=1):
+        check(self._L.fibhip_step(self._h, nticks))
+
+    def step_slow(self):
+        check(self._L.fibhip_step_slow(self._h))
+
+    def pace(self, r0, r1, c0, c1, v, min_v):
+        check(self._L.fibhip_pace(self._h, r0, r1, c0, c1, v, min_v))
+
+    def probe(self, var, row, col):
+        out = C.c_float()
+        check(self._L.fibhip_probe(self._h, var, row, col, C.byref(out)))
+        return np.float32(out.value)
+
+    def sync(self):
+        check(self._L.fibhip_sync(self._h))
+
+    def time_steps(self, nticks):
+        ms, n = C.c_float(), C.c_int()
+        check(self._L.fibhip_time_steps(self._h, nticks, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def step_edges(self):
+        check(self._L.fibhip_step_edges(self._h))
+
+    def step_interior(self):
+        check(self._L.fibhip_step_interior(self._h))
+
+    def step_commit(self):
+        check(self._L.fibhip_step_commit(self._h))
+
+    def state_buf(self, var):
+        p = C.c_void_p()
+        return check(self._L.fibhip_state_ptr(self._h, var, C.byref(p))), p.value
+
+    def next_buf(self, var):
+        p = C.c_void_p()
+        return check(self._L.fibhip_next_ptr(self._h, var, C.byref(p))), p.value
+
+    def halo_vars(self):
+        return check(self._L.fibhip_halo_vars(self._h))
+
+    def launch_plan(self):
+        k, n = C.c_int(), C.c_int()
+        check(self._L.fibhip_launch_plan(self._h, C.byref(k), C.byref(n)))
+        return k.value, n.value

@@ -1,0 +1,133 @@
+"""BeelerReuter — the modified 8-variable Beeler-Reuter ventricular model behind the reference's
+API (siravan/fib_tf `br.py:31-343`).  Device side: csrc/models.hpp `BeelerReuter`.  Host side kept
+here exactly where the reference keeps it: the α/β coefficient table (br.py:49-62) and, for
+config['cheby'], the definition-time least-squares Chebyshev fits and their change of basis
+(br.py:275-287, 303-332), done in NumPy float64 and handed to the kernel as 12x9 float32
+constants."""
+import numpy as np
+
+from . import _lib
+from .ionic import IonicModel
+
+
+class BeelerReuter(IonicModel):
+    MODEL_ID = _lib.BR
+    VAR_NAMES = ('V', 'C', 'M', 'H', 'J', 'D', 'F', 'XI')
+
+    def __init__(self, props):
+        super().__init__(props)
+        self.min_v = -90.0          # mV, br.py:42-44
+        self.max_v = 30.0
+        self.depol = -84.6
+        for key in ('skip', 'cheby'):
+            if not hasattr(self, key):
+                setattr(self, key, False)
+        # rows: ca_x1 cb_x1 ca_m cb_m ca_h cb_h ca_j cb_j ca_d cb_d ca_f cb_f; the d/f rows carry the
+        # factor 2 that halves the calcium gate time constants (br.py:46-62)
+        self.ab_coef = np.array(
+            [[0.0005, 0.083, 50., 0.0, 0.0, 0.057, 1.0],
+             [0.0013, -0.06, 20., 0.0, 0.0, -0.04, 1.0],
+             [0.0000, 0.0, 47., -1.0, 47., -0.1, -1.0],
+             [40., -0.056, 72., 0.0, 0.0, 0.0, 0.0],
+             [0.126, -.25, 77., 0.0, 0.0, 0.0, 0.0],
+             [1.7, 0.0, 22.5, 0.0, 0.0, -0.082, 1.0],
+             [0.055, -.25, 78.0, 0.0, 0.0, -0.2, 1.0],
+             [0.3, 0.0, 32., 0.0, 0.0, -0.1, 1.0],
+             [2 * 0.095, -0.01, -5., 0.0, 0.0, -0.072, 1.0],
+             [2 * 0.07, -0.017, 44., 0.0, 0.0, 0.05, 1.0],
+             [2 * 0.012, -0.008, 28., 0.0, 0.0, 0.15, 1.0],
+             [2 * 0.0065, -0.02, 30., 0.0, 0.0, -0.2, 1.0]],
+            dtype=np.float32)
+
+    def _flags(self):
+        return (super()._flags() | (_lib.CHEBY if self.cheby else 0) | (_lib.SKIP if self.skip else 0))
+
+    # ---- definition-time Chebyshev machinery (host, float64) ------------------------------------
+    def calc_alpha_beta_np(self):
+        """α and β of the six gates sampled at 1001 voltages in [min_v, max_v] (br.py:275-287)"""
+        v = np.linspace(self.min_v, self.max_v, 1001)
+        c = self.ab_coef
+        x = np.outer(v, np.ones(c.shape[0]))
+        y = ((c[:, 0] * np.exp(c[:, 1] * (x + c[:, 2])) + c[:, 3] * (x + c[:, 4])) /
+             (np.exp(c[:, 5] * (x + c[:, 2])) + c[:, 6]))
+        return v, y[..., ::2], y[..., 1::2]
+
+    @staticmethod
+    def leading_term_coefficients(x, y, deg=8):
+        """least-squares Chebyshev fit of y(x), re-expressed in the basis S_i = 2^(i-1) x^i (the
+        leading term of T_i) that the kernel evaluates (br.py:303-327)"""
+        c = np.polynomial.chebyshev.Chebyshev.fit(x, y, deg).coef
+        a = np.zeros([deg + 1, deg + 1], dtype=np.int64)     # a[i, j] = coefficient of x^j in T_i
+        a[0, 0] = 1
+        a[1, 1] = 1
+        for i in range(2, deg + 1):
+            a[i, 1:] += 2 * a[i - 1, :-1]
+            a[i, :] -= a[i - 2, :]
+        a //= np.diag(a)                                      # divide column j by the leading coefficient of T_j
+        return np.matmul(np.transpose(a), c)
+
+    def chebyshev_table(self):
+        """12 x 9 float64 table in the kernel's row order
+        m_inf h_inf m_tau h_tau | xi_inf j_inf d_inf f_inf | xi_tau j_tau d_tau f_tau (br.py:223-240)"""
+        v, al, be = self.calc_alpha_beta_np()
+        rows = []
+        for kind, g in (('inf', 1), ('inf', 2), ('tau', 1), ('tau', 2),
+                        ('inf', 0), ('inf', 3), ('inf', 4), ('inf', 5),
+                        ('tau', 0), ('tau', 3), ('tau', 4), ('tau', 5)):
+            y = al[:, g] / (al[:, g] + be[:, g]) if kind == 'inf' else 1.0 / (al[:, g] + be[:, g])
+            rows.append(self.leading_term_coefficients(v, y, 8))
+        return np.array(rows)
+
+    def _make_stepper(self, steps_per_tick=0):
+        st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
+                          device=self.device, steps_per_tick=steps_per_tick)
+        if self.cheby:
+            st.set_consts(self.chebyshev_table().astype(np.float32))   # each coefficient rounded once
+        if self.phase is not None:
+            st.set_phase(self.phase)
+        return st
+
+    def define(self, s1=True):
+        """initial conditions br.py:71-82 (S1: V[:,1] = 10 mV); one tick = 5 sub-steps, with
+        config['skip'] the slow gates advance 5·dt on the first of them only (br.py:98-107)"""
+        IonicModel.define(self)
+        shape = [self.height, self.width]
+        init = [np.full(shape, v, dtype=np.float32)
+                for v in (-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)]
+        if s1:
+            init[0][:, 1] = 10.0
+        if self._stepper is not None:
+            self._stepper.close()
+        st = self._make_stepper()
+        st.set_state(-1, np.stack(init))
+        self._stepper = st
+        self.dt_per_step = st.steps_per_tick
+        from .ionic import StateVar
+        self._State = {n: StateVar(self, i, n) for i, n in enumerate(self.VAR_NAMES)}
+        self._V = self._State['V']
+
+    def solve(self, state, n=1):
+        """ONE sub-step of (V, C, M, H, J, D, F, XI) host arrays on the GPU (br.py:125-173).
+        n = number of dt the slow gates advance: 1, or 5 (the first sub-step of a skip tick)."""
+        if n not in (1, 5):
+            raise ValueError('solve: n must be 1 or 5 (n=0 only occurs inside a skip tick)')
+        keep = self.skip
+        self.skip = (n == 5)
+        try:
+            st = self._make_stepper(steps_per_tick=1)
+        finally:
+            self.skip = keep
+        try:
+            st.set_state(-1, np.stack([np.asarray(a, np.float32) for a in state]))
+            st.step(1)
+            return tuple(st.get_state(-1))
+        finally:
+            st.close()
+
+    def pot(self):
+        return self._V
+
+    def image(self):
+        """V scaled to 0..1 (br.py:337-343)"""
+        v = self._V.eval()
+        return (v - self.min_v) / (self.max_v - self.min_v)

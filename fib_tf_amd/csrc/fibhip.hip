@@ -1,0 +1,761 @@
+// fibhip.hip — C ABI (include/fibhip.h) over the gfx950 kernels of kernels.hpp.
+//
+// Host-side responsibilities: device memory for the SoA slabs (ping/pong), the per-tick launch
+// plan (how many sub-steps each launch fuses), the per-variable buffer bookkeeping, the
+// edge/interior split used by the row-block multi-GPU driver, and HIP-event timing.
+// There is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fibhip.h"
+#include "kernels.hpp"
+
+using namespace fib;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(...)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (__VA_ARGS__);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(FIBHIP_EHIP, "%s failed: %s (%s:%d)", #__VA_ARGS__, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+extern "C" const char *fibhip_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// kernel variants
+// ------------------------------------------------------------------------------------------
+struct LaunchCtx {
+    Geo g;
+    const float *in[21];
+    float *out[21];
+    PhaseTab ph;
+    const void *consts;
+    int sub0;
+};
+
+typedef hipError_t (*launch_fn)(hipStream_t, const LaunchCtx &);
+
+template <class M, class P, int MODE, int K, int TX, int TY, int NT, bool PHASE>
+static hipError_t launch_tick(hipStream_t st, const LaunchCtx &c)
+{
+    Geo g = c.g;
+    g.tiles_x = (g.W + TX - 1) / TX;
+    const int tiles_y = (g.r1 - g.r0 + TY - 1) / TY;
+    g.ntiles = g.tiles_x * tiles_y;
+    if (g.ntiles <= 0) return hipSuccess;
+    PtrTab<M::NVAR> pt;
+    for (int v = 0; v < M::NVAR; ++v) {
+        pt.in[v] = c.in[v];
+        pt.out[v] = c.out[v];
+    }
+    const int grid = ((g.ntiles + 7) / 8) * 8;       // xcd_tile() needs a multiple of 8
+    hipLaunchKernelGGL((tick_kernel<M, P, MODE, K, TX, TY, NT, PHASE>), dim3(grid), dim3(NT), 0, st, g, pt, c.ph,
+                       *static_cast<const typename M::Consts *>(c.consts), c.sub0);
+    return hipGetLastError();
+}
+
+template <class M, class P, int MODE>
+static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
+{
+    PtrTab<M::NVAR> pt;
+    for (int v = 0; v < M::NVAR; ++v) {
+        pt.in[v] = c.in[v];
+        pt.out[v] = c.out[v];
+    }
+    const long n = (long)(c.g.r1 - c.g.r0) * c.g.W;
+    if (n <= 0) return hipSuccess;
+    const int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL((pointwise_kernel<M, P, MODE>), dim3(grid), dim3(256), 0, st, c.g, pt,
+                       *static_cast<const typename M::Consts *>(c.consts));
+    return hipGetLastError();
+}
+
+struct Variant {
+    int model, mode, fast, phase;
+    int K, TX, TY, NT;
+    launch_fn fn;
+};
+
+#define V4(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
+    {MID, MODE, 0, 0, K, TX, TY, NT, launch_tick<MODEL, Exact, MODE, K, TX, TY, NT, false>},       \
+    {MID, MODE, 0, 1, K, TX, TY, NT, launch_tick<MODEL, Exact, MODE, K, TX, TY, NT, true>},        \
+    {MID, MODE, 1, 0, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, false>},        \
+    {MID, MODE, 1, 1, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, true>}
+
+// The first matching entry with the wanted K is the default; FIBHIP_VARIANT="K,TX,TY,NT" overrides
+// (tuning sweeps).  Tile shapes: K=1 tiles are wide (coalesced 256-B rows); K>1 tiles are square-ish
+// to keep the redundant rim small.
+static const Variant g_variants[] = {
+    // ---- Fenton 4v ----
+    V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 512),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 1024),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 5, 32, 32, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 5, 32, 32, 512),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 5, 32, 16, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 2, 64, 16, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 2, 32, 32, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 4, 256),
+    // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
+    V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 256),
+    V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
+    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
+    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
+    V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 256),
+    V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 512),
+    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 16, 256),
+    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
+    // ---- Courtemanche (mode 0 fast set, 2 all variables) ----
+    V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 4, 256),
+    V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
+    V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
+};
+static const int g_nvariants = (int)(sizeof g_variants / sizeof g_variants[0]);
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct PlanItem {
+    int K;
+    launch_fn fn;
+    int TY;
+};
+
+struct fibhip_ctx {
+    fibhip_desc d;
+    int nvar, spt, mode;
+    size_t cells;
+    hipStream_t s0, s1;
+    bool own_s0;
+    float *slab[2];
+    bool own_slab;
+    float *phase3;          // dpy | dpx | q4, each `cells` floats
+    float *phi_dev;
+    bool has_phase;
+    int cur[21];            // which slab holds variable v
+    int nxt[21];            // where the tick in flight writes it (valid between edges and commit)
+    bool has_consts;
+    Fenton::Consts kf;
+    BeelerReuter::Consts kb;
+    Courtemanche::Consts kc;
+    std::vector<PlanItem> plan;
+    hipEvent_t ev_main, ev_int, ev_t0, ev_t1;
+    int phase_of_tick;      // 0 idle, 1 edges issued, 2 interior issued
+    long launches;
+    int own0, own1;         // owned local rows
+    float *probe_host;      // pinned
+};
+
+static const void *consts_of(fibhip_ctx *h)
+{
+    switch (h->d.model) {
+    case FIBHIP_FENTON4V: return &h->kf;
+    case FIBHIP_BR: return &h->kb;
+    default: return &h->kc;
+    }
+}
+
+extern "C" int fibhip_nvar(int model)
+{
+    switch (model) {
+    case FIBHIP_FENTON4V: return Fenton::NVAR;
+    case FIBHIP_BR: return BeelerReuter::NVAR;
+    case FIBHIP_COURT: return Courtemanche::NVAR;
+    default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
+    }
+}
+
+extern "C" int fibhip_default_steps_per_tick(int model)
+{
+    switch (model) {
+    case FIBHIP_FENTON4V: return Fenton::DEFAULT_STEPS;
+    case FIBHIP_BR: return BeelerReuter::DEFAULT_STEPS;
+    case FIBHIP_COURT: return Courtemanche::DEFAULT_STEPS;
+    default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
+    }
+}
+
+extern "C" int fibhip_abi_version(void) { return FIBHIP_ABI_VERSION; }
+
+extern "C" int fibhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /*TX,TY,NT or null*/)
+{
+    const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
+    for (int i = 0; i < g_nvariants; ++i) {
+        const Variant &v = g_variants[i];
+        if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase || v.K != K) continue;
+        if (want && (v.TX != want[0] || v.TY != want[1] || v.NT != want[2])) continue;
+        return &v;
+    }
+    return nullptr;
+}
+
+// Decompose one tick of `spt` sub-steps into launches.  Default fusion depth per model comes from
+// the measurements recorded in DESIGN.md; FIBHIP_K / FIBHIP_VARIANT override it for sweeps.
+static int build_plan(fibhip_ctx *h)
+{
+    h->plan.clear();
+    int prefK = 0, want[3], nwant = 0;
+    if (const char *e = getenv("FIBHIP_VARIANT")) {
+        int k = 0;
+        if (sscanf(e, "%d,%d,%d,%d", &k, &want[0], &want[1], &want[2]) == 4) {
+            prefK = k;
+            nwant = 1;
+        }
+    }
+    if (!prefK)
+        if (const char *e = getenv("FIBHIP_K")) prefK = atoi(e);
+    if (!prefK) prefK = (h->d.model == FIBHIP_COURT) ? 1 : 5;
+    const int maxghost = (h->d.ghost_top > 0 || h->d.ghost_bottom > 0)
+                             ? (h->d.ghost_top > 0 && h->d.ghost_bottom > 0
+                                    ? (h->d.ghost_top < h->d.ghost_bottom ? h->d.ghost_top : h->d.ghost_bottom)
+                                    : (h->d.ghost_top > 0 ? h->d.ghost_top : h->d.ghost_bottom))
+                             : 1 << 30;
+    int rem = h->spt;
+    while (rem > 0) {
+        const Variant *best = nullptr;
+        for (int K = (prefK < rem ? prefK : rem); K >= 1 && !best; --K) {
+            if (K > maxghost) continue;
+            best = find_variant(h, K, nwant ? want : nullptr);
+            if (!best && nwant) best = find_variant(h, K, nullptr);
+        }
+        if (!best) return fail(FIBHIP_EINVAL, "no kernel variant for model %d mode %d", h->d.model, h->mode);
+        h->plan.push_back({best->K, best->fn, best->TY});
+        rem -= best->K;
+    }
+    return 0;
+}
+
+extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
+{
+    if (!desc || !out) return fail(FIBHIP_EINVAL, "null argument");
+    if (desc->struct_size != (int)sizeof(fibhip_desc))
+        return fail(FIBHIP_EINVAL, "fibhip_desc size mismatch: caller %d, library %d", desc->struct_size,
+                    (int)sizeof(fibhip_desc));
+    const int nv = fibhip_nvar(desc->model);
+    if (nv < 0) return nv;
+    const int Hg = desc->global_height ? desc->global_height : desc->height;
+    if (desc->height < 3 || desc->width < 3 || Hg < 3)
+        return fail(FIBHIP_EINVAL, "grid must be at least 3x3 (got %dx%d)", desc->height, desc->width);
+    if (desc->row_offset < 0 || desc->row_offset + desc->height > Hg || desc->ghost_top < 0 || desc->ghost_bottom < 0 ||
+        desc->ghost_top + desc->ghost_bottom >= desc->height)
+        return fail(FIBHIP_EINVAL, "inconsistent row-block description");
+    if ((desc->ghost_top > 0) != (desc->row_offset > 0) ||
+        (desc->ghost_bottom > 0) != (desc->row_offset + desc->height < Hg))
+        return fail(FIBHIP_EINVAL, "ghost rows must exist exactly on the sides that have a neighbour");
+    if (!(desc->dt > 0.0)) return fail(FIBHIP_EINVAL, "dt must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (desc->device < 0 || desc->device >= ndev) return fail(FIBHIP_EINVAL, "device %d out of range", desc->device);
+    HIPCHK(hipSetDevice(desc->device));
+
+    fibhip_ctx *h = new (std::nothrow) fibhip_ctx();
+    if (!h) return fail(FIBHIP_ENOMEM, "out of host memory");
+    h->d = *desc;
+    h->d.global_height = Hg;
+    h->nvar = nv;
+    h->spt = desc->steps_per_tick > 0 ? desc->steps_per_tick : fibhip_default_steps_per_tick(desc->model);
+    h->cells = (size_t)desc->height * desc->width;
+    h->own0 = desc->ghost_top;
+    h->own1 = desc->height - desc->ghost_bottom;
+    h->mode = 0;
+    if (desc->model == FIBHIP_BR && (desc->flags & FIBHIP_CHEBY)) h->mode = BeelerReuter::MODE_CHEBY;
+    if (desc->model == FIBHIP_COURT)
+        h->mode = (desc->flags & FIBHIP_ALLVARS) ? Courtemanche::MODE_ALL : Courtemanche::MODE_FAST;
+    const int ming = (desc->ghost_top && desc->ghost_bottom)
+                         ? (desc->ghost_top < desc->ghost_bottom ? desc->ghost_top : desc->ghost_bottom)
+                         : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
+    if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt) {
+        delete h;
+        return fail(FIBHIP_EINVAL, "ghost width %d < steps_per_tick %d", ming, h->spt);
+    }
+
+    // scalars: every Python-float product is formed in double and rounded once
+    const double dt = desc->dt, diff = desc->diff;
+    h->kf.dt = (float)dt;
+    h->kf.ddt = (float)(diff * dt);
+    h->kb.dt = (float)dt;
+    h->kb.ddt = (float)(diff * dt);
+    h->kb.mdt = (float)(-dt);
+    h->kb.mdt_skip = (float)(-(dt * 5));
+    h->kb.skip = (desc->flags & FIBHIP_SKIP) ? 1 : 0;
+    memset(h->kb.cheb, 0, sizeof h->kb.cheb);
+    {
+        const bool all = (desc->flags & FIBHIP_ALLVARS) != 0;
+        const double dts = all ? dt : dt * 10;                     // court.py:118-122
+        const double chronic = (desc->flags & FIBHIP_CHRONIC) ? 1.0 : 0.0;
+        h->kc.dtf = (float)dt;
+        h->kc.dts = (float)dts;
+        h->kc.mdt_f = (float)(-dt);
+        h->kc.mdt_s = (float)(-dts);
+        h->kc.ddt = (float)(diff * dt);
+        h->kc.em1_fCa = expm1f((float)(-dts / 2.0));               // tau_f_Ca = 2.0, court.py:160,189
+        h->kc.em1_u = expm1f((float)(-dts / 8.0));                 // tau_u = 8.0,   court.py:161,243
+        h->kc.chronic = (float)chronic;
+        h->kc.c_to = (float)((1.0 - 0.5 * chronic) * 100 * 0.1652);   // court.py:193
+        h->kc.c_Kur = (float)((1.0 - 0.5 * chronic) * 100);           // court.py:194
+        h->kc.c_CaL = (float)((1.0 - 0.7 * chronic) * 100 * 0.12375); // court.py:218
+    }
+    h->has_consts = !(desc->model == FIBHIP_BR && (desc->flags & FIBHIP_CHEBY));
+
+    if (desc->stream) {
+        h->s0 = (hipStream_t)desc->stream;
+        h->own_s0 = false;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&h->s0, hipStreamNonBlocking));
+        h->own_s0 = true;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_int, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&h->ev_t0));
+    HIPCHK(hipEventCreate(&h->ev_t1));
+    const size_t slab_bytes = (size_t)nv * h->cells * sizeof(float);
+    if (desc->ext_slab[0] && desc->ext_slab[1]) {
+        h->slab[0] = (float *)desc->ext_slab[0];
+        h->slab[1] = (float *)desc->ext_slab[1];
+        h->own_slab = false;
+    } else {
+        for (int i = 0; i < 2; ++i) {
+            if (hipMalloc((void **)&h->slab[i], slab_bytes) != hipSuccess) {
+                return fail(FIBHIP_ENOMEM, "hipMalloc of %zu bytes failed", slab_bytes);
+            }
+            HIPCHK(hipMemsetAsync(h->slab[i], 0, slab_bytes, h->s0));
+        }
+        h->own_slab = true;
+    }
+    HIPCHK(hipMalloc((void **)&h->phase3, 3 * h->cells * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&h->phi_dev, h->cells * sizeof(float)));
+    HIPCHK(hipHostMalloc((void **)&h->probe_host, 64, hipHostMallocDefault));
+    h->has_phase = false;
+    for (int v = 0; v < 21; ++v) h->cur[v] = h->nxt[v] = 0;
+    h->phase_of_tick = 0;
+    h->launches = 0;
+    const int rc = build_plan(h);
+    if (rc) {
+        fibhip_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int fibhip_destroy(fibhip_t h)
+{
+    if (!h) return 0;
+    hipSetDevice(h->d.device);
+    hipStreamSynchronize(h->s0);
+    if (h->s1) hipStreamSynchronize(h->s1);
+    if (h->own_slab) {
+        hipFree(h->slab[0]);
+        hipFree(h->slab[1]);
+    }
+    hipFree(h->phase3);
+    hipFree(h->phi_dev);
+    if (h->probe_host) hipHostFree(h->probe_host);
+    if (h->ev_main) hipEventDestroy(h->ev_main);
+    if (h->ev_int) hipEventDestroy(h->ev_int);
+    if (h->ev_t0) hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) hipEventDestroy(h->ev_t1);
+    if (h->s1) hipStreamDestroy(h->s1);
+    if (h->own_s0 && h->s0) hipStreamDestroy(h->s0);
+    delete h;
+    return 0;
+}
+
+static Geo base_geo(const fibhip_ctx *h)
+{
+    Geo g;
+    g.H = h->d.height;
+    g.W = h->d.width;
+    g.Hg = h->d.global_height;
+    g.row_off = h->d.row_offset;
+    g.r0 = 0;
+    g.r1 = h->d.height;
+    g.tiles_x = g.ntiles = 0;
+    return g;
+}
+
+#define NEED(h)                                                  \
+    do {                                                         \
+        if (!(h)) return fail(FIBHIP_EINVAL, "null handle");     \
+        HIPCHK(hipSetDevice((h)->d.device));                     \
+    } while (0)
+
+extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
+{
+    NEED(h);
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_phase inside an open tick");
+    if (!phi) {
+        h->has_phase = false;
+        return build_plan(h);
+    }
+    HIPCHK(hipMemcpyAsync(h->phi_dev, phi, h->cells * sizeof(float), hipMemcpyHostToDevice, h->s0));
+    const Geo g = base_geo(h);
+    hipLaunchKernelGGL(phase_prep_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->phi_dev, h->phase3,
+                       h->phase3 + h->cells, h->phase3 + 2 * h->cells);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->s0));          // `phi` may be a temporary of the caller
+    h->has_phase = true;
+    return build_plan(h);
+}
+
+extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
+{
+    NEED(h);
+    if (!src || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "set_state: bad var %d", var);
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_state inside an open tick");
+    const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
+    for (int v = v0; v < v1; ++v) {
+        const float *s = src + (size_t)(v - v0) * h->cells;
+        for (int b = 0; b < 2; ++b)               // both slabs, so either may become current
+            HIPCHK(hipMemcpyAsync(h->slab[b] + (size_t)v * h->cells, s, h->cells * sizeof(float),
+                                  hipMemcpyHostToDevice, h->s0));
+    }
+    HIPCHK(hipStreamSynchronize(h->s0));
+    return 0;
+}
+
+extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
+{
+    NEED(h);
+    if (!dst || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "get_state: bad var %d", var);
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
+    const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
+    for (int v = v0; v < v1; ++v)
+        HIPCHK(hipMemcpyAsync(dst + (size_t)(v - v0) * h->cells, h->slab[h->cur[v]] + (size_t)v * h->cells,
+                              h->cells * sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(hipStreamSynchronize(h->s0));
+    return 0;
+}
+
+extern "C" int fibhip_set_consts(fibhip_t h, const float *tbl, int n)
+{
+    NEED(h);
+    if (h->d.model != FIBHIP_BR || !(h->d.flags & FIBHIP_CHEBY))
+        return fail(FIBHIP_EINVAL, "set_consts: only the Beeler-Reuter Chebyshev path takes a table");
+    if (!tbl || n != 12 * 9) return fail(FIBHIP_EINVAL, "set_consts: expected 108 coefficients, got %d", n);
+    memcpy(h->kb.cheb, tbl, sizeof h->kb.cheb);
+    h->has_consts = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stepping
+// ------------------------------------------------------------------------------------------
+// Buffer rule for one launch: the potential always ping-pongs (its neighbours are read by other
+// workgroups).  When the launch fuses K > 1 sub-steps every variable ping-pongs, because the halo
+// cells of a tile are owned (and rewritten) by a neighbouring tile.  With K == 1 the pointwise
+// variables are read and written by the same thread only, so they are updated in place — which is
+// also what lets Courtemanche's fast tick assign 4 of its 21 arrays and leave the rest untouched.
+static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *nxt)
+{
+    for (int v = 0; v < h->nvar; ++v) {
+        const bool flip = (v == 0) || (K > 1);
+        nxt[v] = flip ? (cur[v] ^ 1) : cur[v];
+        c.in[v] = h->slab[cur[v]] + (size_t)v * h->cells;
+        c.out[v] = h->slab[nxt[v]] + (size_t)v * h->cells;
+    }
+    c.ph.dpy = h->phase3;
+    c.ph.dpx = h->phase3 + h->cells;
+    c.ph.q4 = h->phase3 + 2 * h->cells;
+    c.consts = consts_of(h);
+}
+
+static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, LaunchCtx &c, int r0, int r1)
+{
+    if (r1 <= r0) return 0;
+    c.g = base_geo(h);
+    c.g.r0 = r0;
+    c.g.r1 = r1;
+    HIPCHK(it.fn(st, c));
+    h->launches++;
+    return 0;
+}
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+// rows launch `l` of the plan has to produce: the owned rows grown by the sub-steps still to come
+// (those rows are the halo of the later launches of the same tick), clipped to the slab
+static void rows_of_launch(const fibhip_ctx *h, size_t l, int &r0, int &r1)
+{
+    int rem = 0;
+    for (size_t m = l + 1; m < h->plan.size(); ++m) rem += h->plan[m].K;
+    r0 = imax(0, h->own0 - (h->d.ghost_top ? rem : 0));
+    r1 = imin(h->d.height, h->own1 + (h->d.ghost_bottom ? rem : 0));
+}
+
+static int check_ready(fibhip_ctx *h)
+{
+    if (!h->has_consts) return fail(FIBHIP_EINVAL, "Chebyshev table not set (fibhip_set_consts)");
+    return 0;
+}
+
+extern "C" int fibhip_step_edges(fibhip_t h)
+{
+    NEED(h);
+    if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step_edges: previous tick not committed");
+    if (int rc = check_ready(h)) return rc;
+    int cur[21];
+    memcpy(cur, h->cur, sizeof cur);
+    int sub = 0;
+    for (size_t l = 0; l < h->plan.size(); ++l) {
+        const PlanItem &it = h->plan[l];
+        LaunchCtx c;
+        int nxt[21];
+        fill_ptrs(h, c, it.K, cur, nxt);
+        c.sub0 = sub;
+        int r0, r1;
+        rows_of_launch(h, l, r0, r1);
+        if (l + 1 < h->plan.size()) {
+            if (int rc = launch_range(h, h->s0, it, c, r0, r1)) return rc;
+            memcpy(cur, nxt, sizeof cur);
+            sub += it.K;
+            continue;
+        }
+        // last launch: only the strips a neighbour is waiting for
+        const int hw = imax(h->d.ghost_top, h->d.ghost_bottom);
+        const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
+        int t1 = h->d.ghost_top ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
+        int b0 = h->d.ghost_bottom ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
+        if (int rc = launch_range(h, h->s0, it, c, r0, t1)) return rc;
+        if (int rc = launch_range(h, h->s0, it, c, b0, r1)) return rc;
+        memcpy(h->nxt, nxt, sizeof nxt);
+    }
+    h->phase_of_tick = 1;
+    return 0;
+}
+
+extern "C" int fibhip_step_interior(fibhip_t h)
+{
+    NEED(h);
+    if (h->phase_of_tick != 1) return fail(FIBHIP_EINVAL, "step_interior: call step_edges first");
+    // recompute the last launch's geometry (same arithmetic as step_edges)
+    int cur[21];
+    memcpy(cur, h->cur, sizeof cur);
+    int sub = 0;
+    for (size_t l = 0; l + 1 < h->plan.size(); ++l) {
+        LaunchCtx tmp;
+        int nxt[21];
+        fill_ptrs(h, tmp, h->plan[l].K, cur, nxt);
+        memcpy(cur, nxt, sizeof cur);
+        sub += h->plan[l].K;
+    }
+    const PlanItem &it = h->plan.back();
+    LaunchCtx c;
+    int nxt[21];
+    fill_ptrs(h, c, it.K, cur, nxt);
+    c.sub0 = sub;
+    int r0, r1;
+    rows_of_launch(h, h->plan.size() - 1, r0, r1);
+    const int hw = imax(h->d.ghost_top, h->d.ghost_bottom);
+    const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
+    const int t1 = h->d.ghost_top ? imin(r0 + e, r1) : r0;
+    const int b0 = h->d.ghost_bottom ? imax(r1 - e, t1) : r1;
+    const bool split = (h->d.ghost_top || h->d.ghost_bottom);
+    hipStream_t st = split ? h->s1 : h->s0;
+    if (split) {
+        // the interior reads what the earlier launches of this tick (and the previous tick's halo
+        // exchange, which the caller ordered on s0) produced
+        HIPCHK(hipEventRecord(h->ev_main, h->s0));
+        HIPCHK(hipStreamWaitEvent(h->s1, h->ev_main, 0));
+    }
+    if (int rc = launch_range(h, st, it, c, t1, b0)) return rc;
+    if (split) HIPCHK(hipEventRecord(h->ev_int, h->s1));
+    h->phase_of_tick = 2;
+    return 0;
+}
+
+extern "C" int fibhip_step_commit(fibhip_t h)
+{
+    NEED(h);
+    if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
+    if (h->d.ghost_top || h->d.ghost_bottom) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
+    memcpy(h->cur, h->nxt, sizeof h->cur);
+    h->phase_of_tick = 0;
+    return 0;
+}
+
+extern "C" int fibhip_step(fibhip_t h, int nticks)
+{
+    NEED(h);
+    if (nticks < 0) return fail(FIBHIP_EINVAL, "negative tick count");
+    for (int t = 0; t < nticks; ++t) {
+        if (int rc = fibhip_step_edges(h)) return rc;
+        if (int rc = fibhip_step_interior(h)) return rc;
+        if (int rc = fibhip_step_commit(h)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int fibhip_step_slow(fibhip_t h)
+{
+    NEED(h);
+    if (h->d.model != FIBHIP_COURT) return fail(FIBHIP_EINVAL, "step_slow: Courtemanche only");
+    if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_slow inside an open tick");
+    LaunchCtx c;
+    for (int v = 0; v < h->nvar; ++v) {
+        c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->cells;
+        c.out[v] = h->slab[h->cur[v]] + (size_t)v * h->cells;     // in place
+    }
+    c.consts = consts_of(h);
+    c.g = base_geo(h);
+    c.g.r0 = h->own0;
+    c.g.r1 = h->own1;
+    c.sub0 = 0;
+    const bool fast = (h->d.flags & FIBHIP_FAST) != 0;
+    launch_fn slow_fn = fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
+                             : launch_pointwise<Courtemanche, Exact, Courtemanche::MODE_SLOW>;
+    HIPCHK(slow_fn(h->s0, c));
+    h->launches++;
+    return 0;
+}
+
+extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, float min_v)
+{
+    NEED(h);
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "pace inside an open tick");
+    const Geo g = base_geo(h);
+    hipLaunchKernelGGL(pace_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->slab[h->cur[0]], r0, r1, c0, c1, v, min_v);
+    HIPCHK(hipGetLastError());
+    h->launches++;
+    return 0;
+}
+
+extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
+{
+    NEED(h);
+    if (!out || var < 0 || var >= h->nvar || row < 0 || row >= h->d.height || col < 0 || col >= h->d.width)
+        return fail(FIBHIP_EINVAL, "probe: out of range");
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "probe inside an open tick");
+    HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->cells + (size_t)row * h->d.width + col,
+                          sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(hipStreamSynchronize(h->s0));
+    *out = *h->probe_host;
+    return 0;
+}
+
+extern "C" int fibhip_sync(fibhip_t h)
+{
+    NEED(h);
+    HIPCHK(hipStreamSynchronize(h->s1));
+    HIPCHK(hipStreamSynchronize(h->s0));
+    return 0;
+}
+
+extern "C" int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int *launches)
+{
+    NEED(h);
+    const long l0 = h->launches;
+    HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+    if (int rc = fibhip_step(h, nticks)) return rc;
+    HIPCHK(hipEventRecord(h->ev_t1, h->s0));
+    HIPCHK(hipEventSynchronize(h->ev_t1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (launches) *launches = (int)(h->launches - l0);
+    return 0;
+}
+
+// IonicModel's building blocks as array ops on HOST arrays (copied through the device), for the
+// unit-level parity tests: op 0 enforce_boundary(a), 1 laplace(a [, phi]), 2 phase_field(pad(a), phi),
+// 3 rush_larsen(a=g, b=g_inf, c=tau, dt).
+extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, const float *b, const float *c,
+                              const float *phi, double dt, int fast, float *out)
+{
+    if (!a || !out || H < 3 || W < 3 || op < 0 || op > 3) return fail(FIBHIP_EINVAL, "unit_op: bad argument");
+    if (op == OP_RUSH_LARSEN && (!b || !c)) return fail(FIBHIP_EINVAL, "unit_op: rush_larsen needs g_inf and tau");
+    if (op == OP_PHASE && !phi) return fail(FIBHIP_EINVAL, "unit_op: phase_field needs phi");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    const size_t n = (size_t)H * W, B = n * sizeof(float);
+    float *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, 8 * B));          // a b c phi ph3[3] out
+    float *da = d, *db = d + n, *dc = d + 2 * n, *dphi = d + 3 * n, *dph3 = d + 4 * n, *dout = d + 7 * n;
+    int rc = 0;
+    do {
+        if (hipMemcpy(da, a, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
+        if (b && hipMemcpy(db, b, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
+        if (c && hipMemcpy(dc, c, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
+        if (phi) {
+            if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
+            Geo g;
+            g.H = g.Hg = H; g.W = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.tiles_x = g.ntiles = 0;
+            hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n);
+        }
+        const float mdt = (float)(-dt);
+        if (fast)
+            hipLaunchKernelGGL(unit_op_kernel<Fast>, dim3(256), dim3(256), 0, 0, op, H, W, da, db, dc, phi ? dph3 : nullptr, mdt, dout);
+        else
+            hipLaunchKernelGGL(unit_op_kernel<Exact>, dim3(256), dim3(256), 0, 0, op, H, W, da, db, dc, phi ? dph3 : nullptr, mdt, dout);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, B, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(FIBHIP_EHIP, "unit_op: kernel or D2H failed");
+            break;
+        }
+    } while (0);
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
+{
+    if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
+    *dev_ptr = h->slab[h->cur[var]] + (size_t)var * h->cells;
+    return h->cur[var];
+}
+
+extern "C" int fibhip_next_ptr(fibhip_t h, int var, void **dev_ptr)
+{
+    if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "next_ptr: bad argument");
+    if (h->phase_of_tick == 0) return fail(FIBHIP_EINVAL, "next_ptr: no tick in flight");
+    *dev_ptr = h->slab[h->nxt[var]] + (size_t)var * h->cells;
+    return h->nxt[var];
+}
+
+extern "C" int fibhip_halo_vars(fibhip_t h)
+{
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    return h->spt > 1 ? h->nvar : 1;
+}
+
+extern "C" int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick)
+{
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    if (fused_steps) *fused_steps = h->plan.empty() ? 0 : h->plan[0].K;
+    if (launches_per_tick) *launches_per_tick = (int)h->plan.size();
+    return 0;
+}

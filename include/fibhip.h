@@ -1,0 +1,152 @@
+/*
+ * fibhip.h — C ABI of libfibhip.so: the MI355X (gfx950) explicit time-stepper for 2D cardiac
+ * reaction-diffusion.
+ *
+ * What this boundary replaces.  The reference (siravan/fib_tf) has no FFI for its hot path:
+ * the lower face of its stepper is `tf.Session.run(op)` on ops built by `define()`
+ * (ionic.py:188-204).  Every entry point below names the reference call it stands in for.
+ * The upper face (IonicModel / define() / run() / add_pace_op() / fire_op() / image()) is
+ * kept in Python (fib_tf_amd/ionic.py ...) and binds these symbols through ctypes
+ * (fib_tf_amd/_lib.py; INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions: plain C, opaque handle, every function returns 0 on success or a negative
+ * FIBHIP_E* code; fibhip_last_error() returns a thread-local message for the last failure.
+ * Host buffers are caller-owned float32, row-major; "slab" = SoA [nvar][height][width].
+ * Work is enqueued asynchronously on the handle's HIP stream; only get/probe/sync/time block.
+ * A handle is not re-entrant.  There is NO CPU fallback: without a HIP device create() fails.
+ *
+ * Variable order (index `var`), as the reference declares its state:
+ *   FENTON4V : U V W S                                   (fenton.py:128-131)
+ *   BR       : V C M H J D F XI                          (br.py:87-94)
+ *   COURT    : V Na_i m h j K_i oa oi ua ui xr xs Ca_i d f f_Ca Ca_rel u v w Ca_up
+ *                                                        (court.py:57-78)
+ * Variable 0 is always the transmembrane potential (the only array the stencil touches).
+ */
+#ifndef FIBHIP_H
+#define FIBHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIBHIP_ABI_VERSION 1
+
+typedef struct fibhip_ctx *fibhip_t;
+
+enum fibhip_model { FIBHIP_FENTON4V = 0, FIBHIP_BR = 1, FIBHIP_COURT = 2 };
+
+enum fibhip_flags {
+    FIBHIP_CHEBY   = 1u << 0, /* BR: Chebyshev gates, config['cheby'] (br.py:132-135); needs set_consts   */
+    FIBHIP_SKIP    = 1u << 1, /* BR: multirate slow gates, config['skip'] (br.py:98-103)                  */
+    FIBHIP_CHRONIC = 1u << 2, /* COURT: self.chronic (court.py:41,167-170)                                */
+    FIBHIP_FAST    = 1u << 3, /* hardware-rate division/exp/tanh instead of the rounding-faithful forms;  */
+                              /* looser parity tolerance, see DESIGN.md                                    */
+    FIBHIP_ALLVARS = 1u << 4  /* COURT: every tick updates all 21 variables with dt (court_ultra.py:      */
+                              /* 107-111,127-128) instead of the fast/slow split                           */
+};
+
+enum fibhip_err {
+    FIBHIP_OK = 0,
+    FIBHIP_EINVAL = -1,   /* bad argument / call order                                   */
+    FIBHIP_EHIP = -2,     /* a HIP runtime call failed (message has the HIP error text)  */
+    FIBHIP_ENODEV = -3,   /* no usable HIP device                                        */
+    FIBHIP_ENOMEM = -4
+};
+
+typedef struct fibhip_desc {
+    int struct_size;     /* sizeof(fibhip_desc): ABI check                                                */
+    int model;           /* enum fibhip_model                                                             */
+    int height, width;   /* rows/cols of THIS handle's slab (for a row block: owned + ghost rows)         */
+    double dt;           /* config['dt']   (fenton.py:159)                                                */
+    double diff;         /* config['diff'] (fenton.py:161); diff*dt is formed in double, rounded once     */
+    unsigned flags;      /* enum fibhip_flags                                                             */
+    int device;          /* HIP device ordinal                                                            */
+    int steps_per_tick;  /* sub-steps one tick advances; 0 = the reference's unroll factor               */
+                         /* (Fenton 10 fenton.py:135-138, BR 5 br.py:98-107, Courtemanche 1 court.py:92)  */
+    /* row-block domain decomposition (all 0 for a single device):                                       */
+    int global_height;   /* rows of the whole grid; 0 = height                                            */
+    int row_offset;      /* global row index of local row 0                                               */
+    int ghost_top;       /* rows at the top of the slab that mirror the upper neighbour's rows            */
+    int ghost_bottom;    /* same at the bottom; a ghost width must be >= steps_per_tick                   */
+    void *stream;        /* hipStream_t to enqueue on (e.g. the caller's torch stream); NULL = own stream */
+    void *ext_slab[2];   /* optional caller-owned DEVICE slabs, each nvar*height*width floats             */
+                         /* (so that the caller can hand them to RCCL); NULL = library allocates          */
+} fibhip_desc;
+
+/* model facts, usable before create: number of state arrays / default steps per tick */
+int fibhip_nvar(int model);
+int fibhip_default_steps_per_tick(int model);
+int fibhip_abi_version(void);
+int fibhip_device_count(void);
+
+/* == define(): tf.Variable creation + graph build (fenton.py:126-147, br.py:85-122, court.py:85-112) */
+int fibhip_create(const fibhip_desc *desc, fibhip_t *out);
+int fibhip_destroy(fibhip_t h);
+
+/* == self.ϕ = tf.Variable(self.phase) (ionic.py:55-57).  phi: host [height*width] (local rows). Must
+ * precede the first step.  NULL removes the phase field.                                               */
+int fibhip_set_phase(fibhip_t h, const float *phi);
+
+/* == tf.Variable(init) / define(state=...) (court.py:87-89).  var = -1: whole slab.                      */
+int fibhip_set_state(fibhip_t h, int var, const float *src);
+
+/* == Variable.eval() (fenton.py:152-153, ionic.py:226-229).  Blocks until preceding ticks are done.     */
+int fibhip_get_state(fibhip_t h, int var, float *dst);
+
+/* == constants baked into the graph at define time.  BR + FIBHIP_CHEBY: the 12x9 float32 table `d` of
+ * br.py:327 in row order m_inf,h_inf,m_tau,h_tau,xi_inf,j_inf,d_inf,f_inf,xi_tau,j_tau,d_tau,f_tau
+ * (br.py:223-240).                                                                                      */
+int fibhip_set_consts(fibhip_t h, const float *tbl, int n);
+
+/* == nticks x sess.run(self._ode_op) (ionic.py:202-203).  Asynchronous.                                  */
+int fibhip_step(fibhip_t h, int nticks);
+
+/* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and
+ * assigns the 17 slow variables.                                                                        */
+int fibhip_step_slow(fibhip_t h);
+
+/* == fire_op(name) of an add_pace_op (ionic.py:144-169): pot = max(pot, s) with s = v inside the GLOBAL
+ * rectangle rows [r0,r1) x cols [c0,c1) and min_v outside.                                              */
+int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, float min_v);
+
+/* == the 'trend' probe (court.py:107-111): one value at LOCAL (row, col).  Blocks.                       */
+int fibhip_probe(fibhip_t h, int var, int row, int col, float *out);
+
+int fibhip_sync(fibhip_t h);
+
+/* Runs `nticks` ticks bracketed by HIP events on the handle's stream and returns the elapsed
+ * milliseconds and the number of kernel launches in between (for the roofline line of bench.py).        */
+int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int *launches);
+
+/* ---- row-block decomposition plumbing (multi-GPU; the halo exchange itself is the caller's RCCL) ----
+ * One tick = step_edges (the tiles that produce the rows a neighbour needs; main stream) +
+ * step_interior (everything else; second stream, concurrent with the caller's halo exchange) +
+ * step_commit (join the streams, flip the ping-pong buffers).  fibhip_step == the three in sequence.   */
+int fibhip_step_edges(fibhip_t h);
+int fibhip_step_interior(fibhip_t h);
+int fibhip_step_commit(fibhip_t h);
+/* Which of the two slabs currently holds `var` AFTER the last commit (0/1), and its device address.
+ * Between step_edges and step_commit, `fibhip_next_ptr` gives the buffer being written.                 */
+int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr);
+int fibhip_next_ptr(fibhip_t h, int var, void **dev_ptr);
+/* number of state arrays whose ghost rows must be refreshed after each tick (all of them when a tick
+ * fuses several sub-steps, only the potential when steps_per_tick == 1)                                 */
+int fibhip_halo_vars(fibhip_t h);
+
+/* IonicModel's public building blocks as stand-alone array ops on HOST arrays [H*W] (unit-level parity):
+ * op 0 = enforce_boundary(a)            ionic.py:107-113
+ *    1 = laplace(a) (+ phase term if phi) ionic.py:44-60
+ *    2 = phase_field(REFLECT-pad(a)), phi ionic.py:70-81
+ *    3 = rush_larsen(a=g, b=g_inf, c=tau, dt)  ionic.py:115-123                                         */
+int fibhip_unit_op(int device, int op, int height, int width, const float *a, const float *b, const float *c,
+                   const float *phi, double dt, int fast, float *out);
+
+/* introspection for DESIGN/bench: sub-steps fused per launch and launches per tick                      */
+int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick);
+
+const char *fibhip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIBHIP_H */

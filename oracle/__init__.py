@@ -65,6 +65,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, None
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_set_threads(host_cores())
     return _lib
 
 
@@ -171,6 +173,25 @@ def court_run(slab, dt, diff, phi, chronic, tick0, nticks, slow_every=10):
     tmp = np.empty(23 * H * W, np.float32); phi = _phi(phi, H, W)
     lib().orc_court_run(H, W, dt, diff, _p(phi), int(chronic), _p(slab), _p(tmp), tick0, nticks, slow_every)
     return slab
+
+
+def host_cores():
+    """cores this process may actually use: affinity mask, cgroup quota, and the GPU box's stated
+    CPU share (16 per GPU) — OpenMP's default of one thread per visible core oversubscribes there"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()
+            if q != 'max':
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    cap = int(os.environ.get('FIBTF_ORACLE_THREADS', '16'))
+    return max(1, min(n, cap))
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def num_threads():

@@ -581,6 +581,15 @@ void orc_court_run(int H, int W, double dt, double diff, const float *phi, int c
     }
 }
 
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

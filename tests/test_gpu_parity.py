@@ -1,0 +1,414 @@
+"""-m gpu: parity of the HIP path (through the ctypes C ABI and the Python API) against
+(a) the committed golden vectors produced by the reference's own functions and (b) the oracle on
+the same seeded inputs.
+
+Tolerances (float32, "Exact" arithmetic policy = one rounding per reference op):
+  * pure arithmetic (boundary, Laplacian, phase field): BIT-EXACT.
+  * one sub-step through tanh/exp/expm1/log: |d| <= 4e-6 * range  (few ulp: ocml vs NumPy/libm).
+  * trajectories: |d| <= 2e-5 * range at <= 200 sub-steps, 1e-3 * range at 1000 sub-steps
+    (round-off grows along the upstroke; beyond wave break the dynamics are chaotic).
+`range` is max_v - min_v of the model (1 for Fenton, 120 mV for BR, 150 mV for Courtemanche);
+gates and concentrations use their own span.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG = {'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'timeline': False, 'timeline_name': 'unused.json',
+       'save_graph': False, 'skip': False, 'cheby': False}
+
+
+def cfg(h, w, diff, **kw):
+    c = dict(CFG, height=h, width=w, diff=diff)
+    c.update(kw)
+    return c
+
+
+def span(a):
+    return max(float(np.max(a) - np.min(a)), 1e-30)
+
+
+def assert_close(got, want, rel, what, scale=None):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert np.isfinite(got).all(), '%s: non-finite values' % what
+    s = scale if scale is not None else max(span(want), float(np.abs(want).max()) * 1e-3, 1e-30)
+    err = float(np.abs(got - want).max())
+    assert err <= rel * s, '%s: max|d| = %.3e > %.1e * %.3g' % (what, err, rel, s)
+
+
+# --------------------------------------------------------------------------------------------
+# unit ops (ionic.py:44-123)
+# --------------------------------------------------------------------------------------------
+def test_unit_ops_bit_exact(gpu_lib, golden):
+    from fib_tf_amd.ionic import IonicModel
+    u = golden('unit_ops')
+    m = IonicModel(cfg(37, 53, 1.0))
+    assert np.array_equal(m.enforce_boundary(u['X']), u['enforce_boundary'])
+    assert np.array_equal(m.laplace(u['X']), u['laplace_nophase'])
+    m.phase = u['phi']
+    assert np.array_equal(m.laplace(u['X']), u['laplace_phase'])
+    assert np.array_equal(m.phase_field(np.pad(u['X'], 1, mode='reflect')), u['phase_field'])
+
+
+def test_rush_larsen(gpu_lib, golden):
+    from fib_tf_amd.ionic import IonicModel
+    u = golden('unit_ops')
+    m = IonicModel(cfg(37, 53, 1.0))
+    for dt in (0.1, 0.5, 1.0):
+        got = m.rush_larsen(u['rl_g'], u['rl_inf'], u['rl_tau'], dt)
+        assert_close(got, u['rush_larsen_dt%g' % dt], 4e-7, 'rush_larsen dt=%g' % dt, scale=1.0)
+    assert m.rush_larsen(np.float32(0.5), 0.2, 3.0, 0.1).shape == ()
+
+
+def test_phase_field_construction(golden):
+    # host-side geometry, no GPU needed but kept next to its consumer
+    from fib_tf_amd.ionic import IonicModel
+    u = golden('unit_ops')
+    m = IonicModel(cfg(37, 53, 1.0))
+    m.add_hole_to_phase_field(20, 15, 6)
+    assert np.array_equal(m.phase, u['hole_a'])
+    m.add_hole_to_phase_field(26, 18, 30, neg=True)
+    assert np.array_equal(m.phase, u['hole_ab'])
+
+
+# --------------------------------------------------------------------------------------------
+# single sub-step vs golden (branch-covering random states)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('variant', ['phase', 'nophase'])
+def test_fenton_single_step(gpu_lib, golden, variant):
+    from fib_tf_amd.fenton import Fenton4v
+    f = golden('fenton_step_' + variant)
+    m = Fenton4v(cfg(37, 53, float(f['diff'])))
+    if f['phase'].size:
+        m.phase = f['phase']
+    out = m.solve(tuple(f[k] for k in 'UVWS'))
+    for k, o in zip('UVWS', out):
+        assert_close(o, f[k + '1'], 4e-6, 'fenton %s1' % k, scale=1.0)
+    # V and W never pass through a transcendental: bit-exact
+    assert np.array_equal(out[1], f['V1'])
+    assert np.array_equal(out[2], f['W1'])
+
+
+@pytest.mark.parametrize('cheby', [False, True])
+@pytest.mark.parametrize('n', [1, 5])
+def test_br_single_step(gpu_lib, golden, cheby, n):
+    from fib_tf_amd.br import BeelerReuter
+    f = golden('br_step')
+    m = BeelerReuter(cfg(37, 53, 0.809, cheby=cheby))
+    m.phase = f['phase']
+    names = m.VAR_NAMES
+    out = m.solve(tuple(f[k] for k in names), n)
+    tag = 'cheby' if cheby else 'direct'
+    for k, o in zip(names, out):
+        want = f['%s1_%s_n%d' % (k, tag, n)]
+        scale = {'V': 120.0, 'C': 1e-5}.get(k, 1.0)
+        assert_close(o, want, 4e-6, 'br %s %s n=%d' % (tag, k, n), scale=scale)
+
+
+SINGULAR = [-10.0001, -10.0, 7.9, -47.13, -14.1, 3.3328, 19.9]
+
+
+@pytest.mark.parametrize('chronic', [True, False])
+def test_court_single_step(gpu_lib, golden, orc, chronic):
+    """all 21 outputs of one solve; cells within 0.06 mV of a removable singularity of calc_inter
+    (court.py:303-410) are compared loosely: there the reference's own formula amplifies one ulp
+    of exp() by 1e4-1e6 (0/0 form), so even NumPy vs libm differ at the 1e-2 level."""
+    from fib_tf_amd.court import Courtemanche
+    f = golden('court_step')
+    m = Courtemanche(cfg(37, 53, 0.809))
+    m.chronic = chronic
+    m.phase = f['phase']
+    out = m.solve({k: f[k] for k in m.VAR_NAMES})
+    V = orc.enforce_boundary(f['V'])
+    near = np.zeros(V.shape, bool)
+    exact = np.zeros(V.shape, bool)
+    for s in SINGULAR:
+        near |= np.abs(V - np.float32(s)) < 0.06
+        exact |= V == np.float32(s)
+    tag = 'chronic' if chronic else 'acute'
+    scales = {'V': 150.0, '_Na_i_': 3.0, '_K_i_': 15.0, '_Ca_i_': 1e-3, '_Ca_rel_': 1.5, '_Ca_up_': 1.0}
+    for k in m.VAR_NAMES:
+        want = f['%s_1_%s' % (k, tag)]
+        sc = scales.get(k, 1.0)
+        d = np.abs(out[k].astype(np.float64) - want)
+        assert np.isfinite(out[k]).all(), k
+        ok = ~near | exact
+        assert d[ok].max() <= 6e-6 * sc, '%s: %.3e' % (k, d[ok].max())
+        assert d.max() <= 0.2 * sc, '%s near singularity: %.3e' % (k, d.max())
+
+
+def test_court_calc_inter_reference_binary(orc):
+    """the oracle's calc_inter against the numbers the reference's own generate_table.cpp prints
+    (compiled from /root/reference into oracle/_ref; output committed as a fixture)"""
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'court_calc_inter_m50.txt')
+    want = np.loadtxt(path)
+    got = orc.court_calc_inter(-50.0)
+    # tau_d (index 3): court.py uses V+10.0001 where courtemanche.h:178-182 uses V+10.0
+    for i, (g, w) in enumerate(zip(got, want)):
+        tol = 5e-6 if i == 3 else 2e-6
+        assert abs(g - w) <= tol * max(abs(w), 1.0) + 6e-7, (i, g, w)
+
+
+# --------------------------------------------------------------------------------------------
+# trajectories through the public API (define / run / fire_op / image) vs golden
+# --------------------------------------------------------------------------------------------
+def run_to(model, ticks, hook=None):
+    """advance `ticks` ticks through model.run()"""
+    model.duration = ticks * model.dt_per_step * model.dt + 1e-9
+    for i in model.run():
+        if hook:
+            hook(i)
+
+
+FENTON_VARIANTS = ['', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512',
+                   '5,32,16,256', '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256']
+
+
+@pytest.mark.parametrize('variant', FENTON_VARIANTS)
+def test_fenton_trajectory_64(gpu_lib, golden, variant, monkeypatch):
+    """64x64 with a hole, ICs from define(); every fusion depth / tile shape must give the SAME
+    answer as the one-step-per-launch kernel (bit-exact) and match the golden trajectory"""
+    from fib_tf_amd.fenton import Fenton4v
+    if variant:
+        monkeypatch.setenv('FIBHIP_VARIANT', variant)
+    f = golden('fenton_traj64')
+    m = Fenton4v(cfg(64, 64, float(f['diff'])))
+    m.add_hole_to_phase_field(*[float(x) for x in f['hole']])
+    assert np.array_equal(m.phase, f['phase'])
+    m.define()
+    for k in 'UVWS':
+        assert np.array_equal(m._State[k].eval(), f['init_' + k])
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        m.duration = (t - t0) * m.dt_per_step * m.dt + 1e-9
+        for _ in m.run():
+            pass
+        t0 = t
+        rel = 2e-5 if t <= 20 else 1e-3
+        for k in 'UVWS':
+            assert_close(m._State[k].eval(), f['%s_t%d' % (k, t)], rel, 'fenton %s tick %d [%s]' % (k, t, variant),
+                         scale=1.0)
+
+
+def test_fenton_fusion_depths_bit_identical(gpu_lib, monkeypatch):
+    """temporal blocking must not change a single bit: K=10/5/2 vs K=1 on a ragged grid with
+    a hole, after 30 sub-steps"""
+    from fib_tf_amd.fenton import Fenton4v
+    res = {}
+    for variant in ('1,64,4,256', '10,32,32,512', '5,32,32,256', '2,64,16,256', '10,32,32,1024'):
+        monkeypatch.setenv('FIBHIP_VARIANT', variant)
+        m = Fenton4v(cfg(45, 70, 1.1))
+        m.add_hole_to_phase_field(30, 20, 7)
+        m.define()
+        run_to(m, 3)
+        res[variant] = np.stack([m._State[k].eval() for k in 'UVWS'])
+    base = res['1,64,4,256']
+    for k, v in res.items():
+        assert np.array_equal(v, base), 'variant %s differs from one-step-per-launch' % k
+
+
+def test_fenton_ragged_nophase(gpu_lib, golden):
+    from fib_tf_amd.fenton import Fenton4v
+    f = golden('fenton_traj_ragged')
+    m = Fenton4v(cfg(45, 70, float(f['diff'])))
+    m.define()
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        run_to(m, t - t0)
+        t0 = t
+        for k in 'UVWS':
+            assert_close(m._State[k].eval(), f['%s_t%d' % (k, t)], 2e-5, 'ragged %s t%d' % (k, t), scale=1.0)
+
+
+def test_fenton_driver_semantics(gpu_lib, golden):
+    """fenton.py __main__ at 96x96: S2 in the left upper quadrant fired at tick 30, image()*phase
+    cube every 10 ticks — pins tick indexing, pacing rectangle and image()"""
+    from fib_tf_amd.fenton import Fenton4v
+    f = golden('fenton_driver96')
+    m = Fenton4v(cfg(96, 96, 1.5, duration=60))
+    m.add_hole_to_phase_field(48, 48, 8)
+    m.define()
+    m.add_pace_op('s2', 'luq', 1.0)
+    s2 = int(f['s2'][0])
+    cube = []
+    for i in m.run():
+        if i == s2:
+            m.fire_op('s2')
+        if i % 10 == 0:
+            cube.append(m.image() * m.phase)
+    assert m.samples == 60 and m.dt_per_step == 10 and m.millisecond_to_step(210) == 210
+    want = f['cube']
+    assert len(cube) == want.shape[0]
+    for j, (g, w) in enumerate(zip(cube, want)):
+        assert_close(g, w, 1e-4 if j < 4 else 1e-3, 'cube frame %d' % j, scale=1.0)
+    for k in 'UVWS':
+        assert_close(m._State[k].eval(), f['%s_t60' % k], 1e-3, 'driver final ' + k, scale=1.0)
+
+
+@pytest.mark.parametrize('name', ['br_traj64_direct', 'br_traj64_cheby', 'br_traj64_skip', 'br_traj64_cheby_skip'])
+@pytest.mark.parametrize('variant', ['', '1,64,4,256', '5,32,32,512'])
+def test_br_trajectory_64(gpu_lib, golden, name, variant, monkeypatch):
+    from fib_tf_amd.br import BeelerReuter
+    if variant:
+        monkeypatch.setenv('FIBHIP_VARIANT', variant)
+    f = golden(name)
+    m = BeelerReuter(cfg(64, 64, float(f['diff']), cheby=bool(f['cheby']), skip=bool(f['skip'])))
+    m.add_hole_to_phase_field(*[float(x) for x in f['hole']])
+    m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
+    for k in m.VAR_NAMES:
+        assert np.array_equal(m._State[k].eval(), f['init_' + k])
+    fire = (lambda i: m.fire_op('s2') if i == 10 else None) if name.endswith('cheby_skip') else None
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        # run() restarts its tick counter: shift the S2 tick accordingly
+        hook = (lambda i, t0=t0: fire(i + t0)) if fire else None
+        run_to(m, t - t0, hook)
+        t0 = t
+        rel = 2e-5 if t <= 20 else 2e-4
+        for k in m.VAR_NAMES:
+            want = f['%s_t%d' % (k, t)]
+            scale = {'V': 120.0, 'C': max(span(want), 1e-7)}.get(k, 1.0)
+            assert_close(m._State[k].eval(), want, rel, '%s %s t%d [%s]' % (name, k, t, variant), scale=scale)
+
+
+@pytest.mark.parametrize('name', ['court_traj64', 'court_traj_ragged'])
+def test_court_trajectory(gpu_lib, golden, name):
+    """fast tick every iteration, 'slow' + 'trend' every 10th (court.py:615-621)"""
+    from fib_tf_amd.court import Courtemanche
+    f = golden(name)
+    H, W = f['phase'].shape
+    m = Courtemanche(cfg(H, W, float(f['diff'])))
+    m.phase = f['phase']
+    m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
+    s2 = 30 if name.endswith('ragged') else -1
+    for k in m.VAR_NAMES:
+        assert np.array_equal(m._State[k].eval(), f['init_' + k])
+    trend = []
+    t0 = 0
+
+    def hook(i):
+        g = i + t0
+        if g % 10 == 0:
+            m.fire_op('slow')
+            m.fire_op('trend')
+            trend.append(m._Trend.eval())
+        if g == s2:
+            m.fire_op('s2')
+
+    scales = {'V': 150.0, '_Na_i_': 1.0, '_K_i_': 1.0, '_Ca_i_': 1e-3, '_Ca_rel_': 1.5, '_Ca_up_': 1.0}
+    # the SR-release gates switch through exp((Fn - 3.4175e-13)/1.367e-15) (court.py:242,246): a
+    # sigmoid so steep that one ulp of Fn moves the release onset; past ~100 ticks the calcium
+    # subsystem of ANY two float32 implementations (NumPy vs libm vs ocml) differs at the 1e-3 level
+    calcium = ('_Ca_i_', '_Ca_rel_', '_Ca_up_', '_u_', '_v_', '_w_', '_f_Ca_')
+    for t in [int(x) for x in f['snap_ticks']]:
+        run_to(m, t - t0, hook)
+        t0 = t
+        for k in m.VAR_NAMES:
+            rel = 2e-5 if t <= 100 else (5e-3 if k in calcium else 2e-4)
+            assert_close(m._State[k].eval(), f['%s_t%d' % (k, t)], rel, '%s %s t%d' % (name, k, t),
+                         scale=scales.get(k, 1.0))
+    want = f['trend']
+    got = np.array(trend)
+    assert got.shape == want.shape
+    assert_close(got[:, 0], want[:, 0], 2e-4, 'trend V', scale=150.0)
+    assert_close(got[:, 1], want[:, 1], 2e-4, 'trend Na_i', scale=1.0)
+
+
+def test_court_keep_state_and_resume(gpu_lib):
+    """run(keep_state=True) -> model.state -> define(state=...) (court.py:615,623-626)"""
+    from fib_tf_amd.court import Courtemanche
+    m1 = Courtemanche(cfg(40, 48, 0.809, duration=2))
+    m1.define()
+    for i in m1.run(keep_state=True):
+        if i % 10 == 0:
+            m1.fire_op('slow')
+    assert set(m1.state) == set(m1.VAR_NAMES)
+    m2 = Courtemanche(cfg(40, 48, 0.809, duration=1))
+    m2.define(state=m1.state)
+    for k in m1.VAR_NAMES:
+        assert np.array_equal(m2._State[k].eval(), m1.state[k])
+
+
+# --------------------------------------------------------------------------------------------
+# oracle comparisons on seeded inputs at sizes the oracle finishes in seconds
+# --------------------------------------------------------------------------------------------
+def test_fenton_vs_oracle_256(gpu_lib, orc):
+    from fib_tf_amd.fenton import Fenton4v
+    m = Fenton4v(cfg(256, 200, 1.5))
+    m.add_hole_to_phase_field(100, 128, 20)
+    m.define()
+    m.add_pace_op('s2', 'luq', 1.0)
+    ref = np.stack([m._State[k].eval() for k in 'UVWS'])
+    run_to(m, 20)
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 200)
+    got = np.stack([m._State[k].eval() for k in 'UVWS'])
+    assert_close(got, ref, 2e-5, 'fenton 256x200, 200 steps', scale=1.0)
+    m.fire_op('s2')
+    r0, r1, c0, c1 = m.pace_rect('luq')
+    ref[0] = orc.pace(ref[0], r0, r1, c0, c1, 1.0, 0.0)
+    assert_close(m._State['U'].eval(), ref[0], 2e-5, 'after S2', scale=1.0)
+
+
+def test_br_vs_oracle_random_state(gpu_lib, orc):
+    """seeded random state, one full tick (5 sub-steps) — both gate paths, both multirate modes"""
+    from fib_tf_amd.br import BeelerReuter
+    rng = np.random.default_rng(7)
+    H, W = 70, 130
+    st = np.empty((8, H, W), np.float32)
+    st[0] = rng.uniform(-85, 25, (H, W))
+    st[1] = np.exp(rng.uniform(np.log(1e-7), np.log(1e-5), (H, W)))
+    st[2:] = rng.uniform(1e-5, 0.99999, (6, H, W))
+    for cheby in (False, True):
+        for skip in (False, True):
+            m = BeelerReuter(cfg(H, W, 0.809, cheby=cheby, skip=skip))
+            m.add_hole_to_phase_field(60, 30, 11)
+            m.define()
+            m._stepper.set_state(-1, st)
+            run_to(m, 1)
+            ref = st.copy()
+            tbl = m.chebyshev_table().astype(np.float32) if cheby else None
+            orc.br_run(ref, 0.1, 0.809, m.phase, tbl, skip, 1)
+            got = m._stepper.get_state()
+            # the degree-8 fits in the scaled-monomial basis cancel ~2 digits (coefficients up to 27,
+            # br.py:289-301): the Chebyshev path is allowed 5x the direct path's tolerance
+            rel = 5e-5 if cheby else 1e-5
+            assert_close(got[0], ref[0], rel, 'br V cheby=%s skip=%s' % (cheby, skip), scale=120.0)
+            assert_close(got[2:], ref[2:], rel, 'br gates', scale=1.0)
+            assert_close(got[1], ref[1], rel, 'br C', scale=1e-5)
+
+
+def test_pace_locations(gpu_lib, orc):
+    from fib_tf_amd.fenton import Fenton4v
+    for loc in ('left', 'right', 'top', 'bottom', 'luq', 'llq', 'ruq', 'rlq', 'nowhere'):
+        m = Fenton4v(cfg(23, 31, 1.0))
+        m.define(s1=False)
+        rng = np.random.default_rng(3)
+        u = rng.uniform(-0.2, 0.9, (23, 31)).astype(np.float32)
+        m._stepper.set_state(0, u)
+        m.add_pace_op('p', loc, 0.7)
+        m.fire_op('p')
+        s = np.full((23, 31), m.min_v, np.float32)
+        H, W = 23, 31
+        sl = {'left': (slice(None), slice(None, 5)), 'right': (slice(None), slice(-5, None)),
+              'top': (slice(None, 5), slice(None)), 'bottom': (slice(-5, None), slice(None)),
+              'luq': (slice(1, H // 2), slice(1, W // 2)), 'llq': (slice(H // 2, -1), slice(1, W // 2)),
+              'ruq': (slice(1, H // 2), slice(W // 2, -1)), 'rlq': (slice(H // 2, -1), slice(W // 2, -1))}
+        if loc in sl:
+            s[sl[loc]] = 0.7
+        assert np.array_equal(m._State['U'].eval(), np.maximum(u, s)), loc
+
+
+def test_api_guards():
+    from fib_tf_amd.fenton import Fenton4v
+    m = Fenton4v(cfg(16, 16, 1.0))
+    with pytest.raises(AssertionError):
+        m.add_pace_op('s2', 'luq', 1.0)          # before define, ionic.py:141-142
+    m.defined = True
+    with pytest.raises(AssertionError):
+        m.add_hole_to_phase_field(8, 8, 2)       # after define, ionic.py:92-93
