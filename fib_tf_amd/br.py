@@ -78,14 +78,9 @@ class BeelerReuter(IonicModel):
             rows.append(self.leading_term_coefficients(v, y, 8))
         return np.array(rows)
 
-    def _make_stepper(self, steps_per_tick=0):
-        st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
-                          device=self.device, steps_per_tick=steps_per_tick)
+    def _configure_stepper(self, st):
         if self.cheby:
             st.set_consts(self.chebyshev_table().astype(np.float32))   # each coefficient rounded once
-        if self.phase is not None:
-            st.set_phase(self.phase)
-        return st
 
     def define(self, s1=True):
         """initial conditions br.py:71-82 (S1: V[:,1] = 10 mV); one tick = 5 sub-steps, with
@@ -96,14 +91,7 @@ class BeelerReuter(IonicModel):
                 for v in (-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)]
         if s1:
             init[0][:, 1] = 10.0
-        if self._stepper is not None:
-            self._stepper.close()
-        st = self._make_stepper()
-        st.set_state(-1, np.stack(init))
-        self._stepper = st
-        self.dt_per_step = st.steps_per_tick
-        from .ionic import StateVar
-        self._State = {n: StateVar(self, i, n) for i, n in enumerate(self.VAR_NAMES)}
+        self._create(init)
         self._V = self._State['V']
 
     def solve(self, state, n=1):
@@ -114,7 +102,7 @@ class BeelerReuter(IonicModel):
         keep = self.skip
         self.skip = (n == 5)
         try:
-            st = self._make_stepper(steps_per_tick=1)
+            st = self._new_stepper(steps_per_tick=1, shard=False)
         finally:
             self.skip = keep
         try:

@@ -78,12 +78,9 @@ class Courtemanche(IonicModel):
         arrs = np.stack([np.asarray(State[n], np.float32) for n in self.VAR_NAMES])
         out = {}
         for which in ('fast', 'slow'):
-            st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
-                              device=self.device, steps_per_tick=1)
+            st = self._new_stepper(steps_per_tick=1, shard=False)
             try:
                 st.set_state(-1, arrs)
-                if self.phase is not None:
-                    st.set_phase(self.phase)
                 st.step(1) if which == 'fast' else st.step_slow()
                 res = st.get_state(-1)
             finally:

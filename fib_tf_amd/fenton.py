@@ -34,12 +34,9 @@ class Fenton4v(IonicModel):
 
     def solve(self, state):
         """ONE explicit-Euler sub-step of (U, V, W, S) host arrays on the GPU (fenton.py:95-108)"""
-        st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
-                          device=self.device, steps_per_tick=1)
+        st = self._new_stepper(steps_per_tick=1, shard=False)
         try:
             st.set_state(-1, np.stack([np.asarray(a, np.float32) for a in state]))
-            if self.phase is not None:
-                st.set_phase(self.phase)
             st.step(1)
             return tuple(st.get_state(-1))
         finally:

@@ -17,6 +17,7 @@ handle whose state lives as one SoA slab in HBM; one `run()` tick is one call of
 All numerical work happens in the HIP library; there is no CPU fallback here.
 """
 import json
+import os
 import time
 
 import numpy as np
@@ -56,7 +57,7 @@ class IonicModel:
         self._stepper = None
         self._sess_open = False
         for key, default in (('timeline', False), ('timeline_name', 'timeline.json'), ('save_graph', False),
-                             ('device', 0), ('fast_math', False)):
+                             ('device', int(os.environ.get('LOCAL_RANK', '0'))), ('fast_math', False)):
             if not hasattr(self, key):
                 setattr(self, key, default)
 
@@ -209,15 +210,32 @@ class IonicModel:
     def _flags(self):
         return _lib.FAST if self.fast_math else 0
 
+    def _new_stepper(self, steps_per_tick=0, shard=True):
+        """a fibhip handle for the whole grid, or — when a torch.distributed process group with more
+        than one rank is initialised — this rank's row block of it (fib_tf_amd/sharded.py)"""
+        from .sharded import ShardedStepper, dist_world
+        _, world = dist_world()
+        if shard and world > 1:
+            st = ShardedStepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
+                                device=self.device, steps_per_tick=steps_per_tick,
+                                engine_factory=getattr(self, 'engine_factory', None))
+        else:
+            st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
+                              device=self.device, steps_per_tick=steps_per_tick)
+        self._configure_stepper(st)
+        if self.phase is not None:
+            st.set_phase(self.phase)
+        return st
+
+    def _configure_stepper(self, st):
+        """model-specific constants (BeelerReuter: the Chebyshev table)"""
+
     def _create(self, init_arrays, steps_per_tick=0):
         """init_arrays: list of [H,W] float32 in the model's variable order"""
         if self._stepper is not None:
             self._stepper.close()
-        st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
-                          device=self.device, steps_per_tick=steps_per_tick)
+        st = self._new_stepper(steps_per_tick)
         st.set_state(-1, np.stack([np.asarray(a, np.float32) for a in init_arrays]))
-        if self.phase is not None:
-            st.set_phase(self.phase)
         self._stepper = st
         self.dt_per_step = st.steps_per_tick
         self._State = {n: StateVar(self, i, n) for i, n in enumerate(self.VAR_NAMES)}

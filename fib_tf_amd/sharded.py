@@ -1,0 +1,326 @@
+"""Row-block domain decomposition across the GPUs of one node: one process per GPU
+(`torch.distributed`, backend "nccl" = RCCL over xGMI), one fibhip handle per process.
+
+Decomposition.  Rank r owns a contiguous block of rows of every state array and keeps
+`g = steps_per_tick` ghost rows of its upper and lower neighbour.  A tick advances g sub-steps;
+the kernels recompute the rim redundantly (temporal blocking, kernels.hpp), so ONE exchange per tick
+suffices: each rank sends the g outermost owned rows of the updated arrays to the neighbour and
+receives the neighbour's into its ghost rows — a pair of point-to-point messages per neighbour, no
+collective on the data path.  (All arrays travel when a tick fuses several sub-steps; with one
+sub-step per tick — Courtemanche — only the potential does.)
+
+Overlap.  `step_edges` computes the strips the neighbours wait for on the main stream; the sends
+are posted right behind them; `step_interior` runs the bulk of the block on a second HIP stream
+while the messages are on the wire; `step_commit` joins the two.
+
+PyTorch is plumbing here: it owns the two device slabs (so RCCL can address them), the stream and
+the process group.  The arithmetic is libfibhip's.  The `engine_factory` hook exists so that the
+host logic of this file (slicing, exchange, gather) can be exercised on CPU tensors with gloo; the
+product default is the HIP engine and nothing else.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def dist_world():
+    """(rank, world) of the initialised default process group, or (0, 1)"""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def row_blocks(height, world):
+    """[(first_row, n_rows)] per rank: as even as possible, earlier ranks take the remainder"""
+    base, rem = divmod(height, world)
+    out, r0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((r0, n))
+        r0 += n
+    return out
+
+
+class HipEngine:
+    """the product engine: a fibhip handle on torch-owned device slabs and torch's current stream"""
+
+    def __init__(self, model_id, height, width, dt, diff, flags, steps_per_tick, global_height, row_offset,
+                 ghost_top, ghost_bottom, device):
+        import torch
+        self.torch = torch
+        self.dev = torch.device('cuda', device)
+        nvar = _lib.check(_lib.lib().fibhip_nvar(model_id))
+        self.slabs = [torch.zeros((nvar, height, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        # a stream of our own (torch's default stream has the null handle, which fibhip reads as
+        # "create one"): kernels, halo packing and RCCL's stream dependencies all hang off this one
+        self.stream = torch.cuda.Stream(self.dev)
+        torch.cuda.synchronize(self.dev)                    # the zero-fill above ran on the default stream
+        stream = self.stream.cuda_stream
+        self.st = _lib.Stepper(model_id, height, width, dt, diff, flags=flags, device=device,
+                               steps_per_tick=steps_per_tick, global_height=global_height, row_offset=row_offset,
+                               ghost_top=ghost_top, ghost_bottom=ghost_bottom, stream=stream,
+                               ext_slabs=(self.slabs[0].data_ptr(), self.slabs[1].data_ptr()))
+        self.nvar = nvar
+
+    # thin forwards
+    def __getattr__(self, name):
+        return getattr(self.st, name)
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def from_host(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
+
+    def empty(self, shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device=self.dev)
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def device_sync(self):
+        self.st.sync()
+        self.torch.cuda.synchronize(self.dev)
+
+
+class ShardedStepper:
+    """same surface as `_lib.Stepper`, for one row block of a grid shared by all ranks"""
+
+    def __init__(self, model_id, height, width, dt, diff, flags=0, device=0, steps_per_tick=0,
+                 engine_factory=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.H, self.width = height, width
+        self.height = height                               # global, like Stepper.height for one device
+        L = None
+        if engine_factory is None:
+            L = _lib.lib()
+            nvar = _lib.check(L.fibhip_nvar(model_id))
+            spt = steps_per_tick or _lib.check(L.fibhip_default_steps_per_tick(model_id))
+        else:
+            nvar, spt = engine_factory.nvar(model_id), steps_per_tick or engine_factory.default_steps(model_id)
+        self.nvar, self.steps_per_tick = nvar, spt
+        self.blocks = row_blocks(height, self.world)
+        self.row0, self.rows = self.blocks[self.rank]
+        if min(n for _, n in self.blocks) < max(spt, 2):
+            raise ValueError('row blocks of %d rows are thinner than the %d-row halo: use fewer ranks or a taller '
+                             'grid' % (min(n for _, n in self.blocks), spt))
+        self.g = spt
+        self.gt = self.g if self.rank > 0 else 0
+        self.gb = self.g if self.rank < self.world - 1 else 0
+        self.lo = self.row0 - self.gt                       # global row of local row 0
+        self.lh = self.rows + self.gt + self.gb             # local slab height
+        factory = engine_factory or HipEngine
+        self.eng = factory(model_id, self.lh, width, dt, diff, flags, spt, height, self.lo, self.gt, self.gb, device)
+        self.halo_n = self.eng.halo_vars()
+        self.up = self.rank - 1 if self.rank > 0 else None
+        self.down = self.rank + 1 if self.rank < self.world - 1 else None
+        # RCCL moves device buffers directly.  A backend without device point-to-point (gloo: used to
+        # rehearse this driver with several ranks on ONE GPU, and by the CPU tests) gets host staging.
+        self.staged = dist.get_backend(group) != 'nccl'
+        shape = (self.halo_n, self.g, width)
+        mk = (lambda: torch.empty(shape, dtype=torch.float32)) if self.staged else (lambda: self.eng.empty(shape))
+        self.recv_up = mk() if self.up is not None else None
+        self.recv_down = mk() if self.down is not None else None
+        self.comm_s = 0.0
+
+    # ---- data movement between the global arrays and this block ---------------------------------
+    def _local(self, arr):
+        return np.ascontiguousarray(arr[..., self.lo:self.lo + self.lh, :], dtype=np.float32)
+
+    def set_phase(self, phi):
+        self.eng.set_phase(None if phi is None else self._local(np.asarray(phi)))
+
+    def set_state(self, var, arr):
+        self.eng.set_state(var, self._local(np.asarray(arr)))
+
+    def get_state(self, var=-1):
+        """the WHOLE array(s), gathered on every rank (image()/eval() are global in the reference)"""
+        torch, dist = self.torch, self.dist
+        local = self.eng.get_state(var)                                    # numpy, local rows
+        own = local[..., self.gt:self.gt + self.rows, :]
+        maxr = max(n for _, n in self.blocks)
+        lead = own.shape[:-2]
+        pad = np.zeros(lead + (maxr, self.width), np.float32)
+        pad[..., :self.rows, :] = own
+        mine = torch.from_numpy(pad) if self.staged else self.eng.from_host(pad)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        out = np.empty(lead + (self.H, self.width), np.float32)
+        for (r0, n), p in zip(self.blocks, parts):
+            out[..., r0:r0 + n, :] = p.cpu().numpy()[..., :n, :]
+        return out
+
+    def set_consts(self, tbl):
+        self.eng.set_consts(tbl)
+
+    # ---- one tick ----------------------------------------------------------------------------------
+    def _slab_view(self, var, nxt):
+        idx, _ = self.eng.next_buf(var) if nxt else self.eng.state_buf(var)
+        return self.eng.slabs[idx][var]
+
+    def _tick(self):
+        with self.eng.stream_ctx():
+            self._tick_on_stream()
+
+    def _tick_on_stream(self):
+        torch, dist, e, g = self.torch, self.dist, self.eng, self.g
+        e.step_edges()
+        t0 = time.perf_counter()
+        ops, keep = [], []
+        if self.up is not None:
+            s = torch.stack([self._slab_view(v, True)[self.gt:self.gt + g] for v in range(self.halo_n)])
+            s = s.cpu() if self.staged else s
+            keep.append(s)
+            ops += [dist.P2POp(dist.isend, s, self.up, self.group), dist.P2POp(dist.irecv, self.recv_up, self.up, self.group)]
+        if self.down is not None:
+            b = self.gt + self.rows
+            s = torch.stack([self._slab_view(v, True)[b - g:b] for v in range(self.halo_n)])
+            s = s.cpu() if self.staged else s
+            keep.append(s)
+            ops += [dist.P2POp(dist.isend, s, self.down, self.group),
+                    dist.P2POp(dist.irecv, self.recv_down, self.down, self.group)]
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        e.step_interior()                                   # overlaps with the messages
+        for r in reqs:
+            r.wait()
+        for v in range(self.halo_n):
+            if self.up is not None:
+                self._slab_view(v, True)[:g].copy_(self.recv_up[v])
+            if self.down is not None:
+                self._slab_view(v, True)[self.gt + self.rows:].copy_(self.recv_down[v])
+        self.comm_s += time.perf_counter() - t0
+        e.step_commit()
+
+    def step(self, nticks=1):
+        for _ in range(nticks):
+            self._tick()
+
+    def step_slow(self):
+        self.eng.step_slow()                                # pointwise: no halo needed
+
+    def pace(self, r0, r1, c0, c1, v, min_v):
+        self.eng.pace(r0, r1, c0, c1, v, min_v)             # global rectangle; the kernel offsets rows
+
+    def probe(self, var, row, col):
+        owner = next(i for i, (r0, n) in enumerate(self.blocks) if r0 <= row < r0 + n)
+        val = self.torch.zeros((1,), dtype=self.torch.float32) if self.staged else self.eng.empty((1,))
+        if owner == self.rank:
+            val.fill_(float(self.eng.probe(var, row - self.lo, col)))
+        self.dist.broadcast(val, owner, group=self.group)
+        return np.float32(val.cpu().numpy()[0])
+
+    def sync(self):
+        self.eng.device_sync()
+
+    def time_steps(self, nticks):
+        self.sync()
+        self.dist.barrier(group=self.group)
+        l0 = self.launches()
+        t0 = time.perf_counter()
+        self.step(nticks)
+        self.sync()
+        return (time.perf_counter() - t0) * 1e3, self.launches() - l0
+
+    def launches(self):
+        return getattr(self.eng, 'launch_count', lambda: 0)()
+
+    def launch_plan(self):
+        return self.eng.launch_plan()
+
+    def close(self):
+        if hasattr(self.eng, 'close'):
+            self.eng.close()
+
+
+def init_from_env():
+    """process group + device for a rank started by `python -m torch.distributed.run`"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    return rank, world, local
+
+
+def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
+    """bench.py --gpus N: weak scaling, every rank owns `rows_per_gpu` rows of a (rows_per_gpu*N) x size grid"""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = init_from_env()
+    H = args.rows_per_gpu * world
+    m, (loc, amp, s2_ms) = make_model(args, height=H, device=local)
+    m.define()
+    m.add_pace_op('s2', loc, amp)
+    s2 = m.millisecond_to_step(s2_ms)
+    st = m._stepper
+    spt = m.dt_per_step
+    court = args.model == 'court'
+    tick = 0
+
+    def advance(n):
+        nonlocal tick
+        for _ in range(n):
+            st.step(1)
+            if court and tick % 10 == 0:
+                st.step_slow()
+            if tick == s2:
+                m.fire_op('s2')
+            tick += 1
+
+    advance(args.warmup)
+    st.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    advance(args.steps)
+    st.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    comm = torch.tensor([st.comm_s], dtype=torch.float64, device='cuda')
+    dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+    fused, per_tick = st.launch_plan()
+    out = None
+    if rank == 0:
+        cells = H * m.width
+        value = cells * args.steps * spt / wall / 1e6
+        abytes = algo_bytes[args.model] + (4 if m.phase is not None else 0)
+        us_tick = wall * 1e6 / args.steps
+        achieved = abytes * (cells / world) * spt / (us_tick * 1e-6) / 1e9
+        out = {
+            'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d over %d GPUs' % (
+                args.model, H, m.width, world),
+            'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(wall * 1000.0 / args.steps, 6), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d grid = %d rows x %d cols per GPU (weak scaling of BASELINE configs[1] by '
+                                   'rows), dt=0.1 ms, phase-field hole, S1 + S2; 1 step = 1 tick = %d sub-steps'
+                                   % (args.model, H, m.width, args.rows_per_gpu, m.width, spt),
+                       'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
+                       'parallelism': 'row-block x%d, %d-row halo of %d arrays per tick as RCCL send/recv, interior '
+                                      'overlapped on a second stream' % (world, st.g, st.halo_n),
+                       'halo_wait_s_max_rank': round(float(comm.item()), 4)},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': hbm_peak, 'unit': 'GB/s',
+                         'frac': round(achieved / hbm_peak, 4), 'traffic': None,
+                         'note': 'per GPU, whole tick incl. halo exchange (wall / ticks); kernel-only figure: N=1 line'},
+        }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out

@@ -1,0 +1,51 @@
+"""worker for tests/test_sharded_cpu.py: one gloo rank running the product's sharded driver
+(fib_tf_amd/sharded.py + the model classes) over the CPU test engine"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run_case(rank, world, port, case, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cpu_engine import OracleEngine
+        from fib_tf_amd.fenton import Fenton4v
+        from fib_tf_amd.br import BeelerReuter
+        from fib_tf_amd.court import Courtemanche
+        H, W, ticks = case['H'], case['W'], case['ticks']
+        cfg = {'height': H, 'width': W, 'dt': 0.1, 'dt_per_plot': 10, 'diff': case['diff'], 'duration': 1000,
+               'cheby': case.get('cheby', False), 'skip': case.get('skip', False)}
+        if case.get('engine', 'oracle') == 'oracle':
+            cfg['engine_factory'] = OracleEngine         # CPU rehearsal; otherwise the HIP engine on device 0
+        else:
+            cfg['device'] = 0
+        cls = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']]
+        m = cls(cfg)
+        m.add_hole_to_phase_field(*case['hole'])
+        m.define()
+        m.add_pace_op('s2', 'luq', case['amp'])
+        m.duration = ticks * m.dt_per_step * m.dt + 1e-9
+        trend = []
+        for i in m.run():
+            if case['model'] == 'court' and i % 10 == 0:
+                m.fire_op('slow')
+                m.fire_op('trend')
+                trend.append(m._Trend.eval())
+            if i == case['s2']:
+                m.fire_op('s2')
+        full = np.stack([m._State[n].eval() for n in m.VAR_NAMES])
+        img = m.image()
+        if rank == 0:
+            np.savez(os.path.join(outdir, 'out.npz'), full=full, img=img, trend=np.array(trend, np.float32),
+                     blocks=np.array(m._stepper.blocks))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()

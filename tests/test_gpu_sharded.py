@@ -1,0 +1,56 @@
+"""-m gpu: the row-block driver with the REAL HIP engine.  The GPU box has one MI355X, so two (and
+three) ranks share device 0 and exchange halos through gloo with host staging (RCCL refuses two
+ranks on one device); everything else is the production path: torch-owned slabs handed to fibhip as
+ext_slab, ghost rows, row_offset-aware kernels, step_edges / step_interior on two streams /
+step_commit.  The gathered result must be BITWISE equal to the single-handle run on the same GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_sharded_cpu import launch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (2, {'model': 'fenton', 'H': 128, 'W': 96, 'diff': 1.5, 'hole': (40, 64, 9), 'ticks': 12, 's2': 5, 'amp': 1.0}),
+    (3, {'model': 'fenton', 'H': 131, 'W': 70, 'diff': 1.1, 'hole': (30, 50, 7), 'ticks': 7, 's2': 2, 'amp': 1.0}),
+    (2, {'model': 'br', 'H': 90, 'W': 77, 'diff': 0.809, 'hole': (30, 40, 8), 'ticks': 9, 's2': 4, 'amp': 10.0,
+         'cheby': True, 'skip': False}),
+    (3, {'model': 'br', 'H': 100, 'W': 64, 'diff': 0.809, 'hole': (30, 40, 8), 'ticks': 6, 's2': 3, 'amp': 10.0,
+         'cheby': False, 'skip': True}),
+    (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 25, 's2': 12, 'amp': 10.0}),
+]
+
+
+def single(case):
+    from fib_tf_amd.fenton import Fenton4v
+    from fib_tf_amd.br import BeelerReuter
+    from fib_tf_amd.court import Courtemanche
+    cfg = {'height': case['H'], 'width': case['W'], 'dt': 0.1, 'dt_per_plot': 10, 'diff': case['diff'],
+           'duration': 1000, 'cheby': case.get('cheby', False), 'skip': case.get('skip', False)}
+    m = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']](cfg)
+    m.add_hole_to_phase_field(*case['hole'])
+    m.define()
+    m.add_pace_op('s2', 'luq', case['amp'])
+    m.duration = case['ticks'] * m.dt_per_step * m.dt + 1e-9
+    trend = []
+    for i in m.run():
+        if case['model'] == 'court' and i % 10 == 0:
+            m.fire_op('slow')
+            m.fire_op('trend')
+            trend.append(m._Trend.eval())
+        if i == case['s2']:
+            m.fire_op('s2')
+    return np.stack([m._State[n].eval() for n in m.VAR_NAMES]), np.array(trend, np.float32)
+
+
+@pytest.mark.parametrize('world,case', CASES, ids=['%s-x%d' % (c['model'], w) for w, c in CASES])
+def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path):
+    want, trend = single(case)
+    out = launch(world, dict(case, engine='hip'), tmp_path)
+    assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
+    if case['model'] == 'court':
+        assert np.array_equal(out['trend'], trend)

@@ -1,0 +1,125 @@
+"""not-gpu: the multi-rank path (fib_tf_amd/sharded.py) with world_size 2 and 3 over gloo on CPU.
+The product's own host logic runs — row slicing, ghost rows, batched isend/irecv halo exchange,
+gather for image()/eval(), pacing in global coordinates, the model classes' run() loop — with the
+CPU test engine (tests/cpu_engine.py, oracle arithmetic) in place of the HIP engine.
+Expectation: the gathered N-rank result is BITWISE equal to the single-domain oracle run."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, case, tmp_path):
+    from sharded_worker import run_case
+    ctx = mp.get_context('spawn')
+    port = free_port()
+    procs = [ctx.Process(target=run_case, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail('rank hung')
+        assert p.exitcode == 0
+    return np.load(os.path.join(str(tmp_path), 'out.npz'))
+
+
+def single_domain(case, orc):
+    from fib_tf_amd.ionic import IonicModel
+    H, W = case['H'], case['W']
+    g = IonicModel({'height': H, 'width': W})
+    g.add_hole_to_phase_field(*case['hole'])
+    rect = g.pace_rect('luq')
+    if case['model'] == 'fenton':
+        s = np.zeros((4, H, W), np.float32)
+        s[1:3] = 1.0
+        s[0][:, 1] = 1.0
+        for i in range(case['ticks']):
+            orc.fenton_run(s, 0.1, case['diff'], g.phase, 10)
+            if i == case['s2']:
+                s[0] = orc.pace(s[0], *rect, case['amp'], 0.0)
+        return s, None
+    if case['model'] == 'br':
+        from fib_tf_amd.br import BeelerReuter
+        s = np.empty((8, H, W), np.float32)
+        for i, v in enumerate((-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)):
+            s[i] = v
+        s[0][:, 1] = 10.0
+        tbl = BeelerReuter({'height': 8, 'width': 8}).chebyshev_table().astype(np.float32) if case['cheby'] else None
+        for i in range(case['ticks']):
+            orc.br_run(s, 0.1, case['diff'], g.phase, tbl, case['skip'], 1)
+            if i == case['s2']:
+                s[0] = orc.pace(s[0], *rect, case['amp'], -90.0)
+        return s, None
+    from fib_tf_amd.court import INITIAL
+    s = np.empty((21, H, W), np.float32)
+    for i, (_, v) in enumerate(INITIAL):
+        s[i] = v
+    s[0][:, :25] = 20.0
+    trend = []
+    for i in range(case['ticks']):
+        orc.court_run(s, 0.1, case['diff'], g.phase, True, i, 1)
+        if i % 10 == 0:
+            trend.append([s[0][W // 2, 20], s[1][W // 2, 20]])
+        if i == case['s2']:
+            s[0] = orc.pace(s[0], *rect, case['amp'], -100.0)
+    return s, np.array(trend, np.float32)
+
+
+CASES = [
+    (2, {'model': 'fenton', 'H': 48, 'W': 40, 'diff': 1.5, 'hole': (20, 24, 5), 'ticks': 6, 's2': 3, 'amp': 1.0}),
+    (3, {'model': 'fenton', 'H': 50, 'W': 37, 'diff': 1.1, 'hole': (18, 30, 4), 'ticks': 4, 's2': 1, 'amp': 1.0}),
+    (2, {'model': 'br', 'H': 30, 'W': 44, 'diff': 0.809, 'hole': (20, 12, 4), 'ticks': 8, 's2': 4, 'amp': 10.0,
+         'cheby': True, 'skip': False}),
+    (3, {'model': 'br', 'H': 33, 'W': 25, 'diff': 0.809, 'hole': (10, 15, 4), 'ticks': 6, 's2': 2, 'amp': 10.0,
+         'cheby': False, 'skip': True}),
+    (2, {'model': 'court', 'H': 60, 'W': 56, 'diff': 0.809, 'hole': (28, 30, 5), 'ticks': 25, 's2': 12, 'amp': 10.0}),
+]
+
+
+@pytest.mark.parametrize('world,case', CASES, ids=['%s-x%d' % (c['model'], w) for w, c in CASES])
+def test_sharded_equals_single_domain(world, case, tmp_path, orc):
+    out = launch(world, case, tmp_path)
+    want, trend = single_domain(case, orc)
+    assert out['blocks'].shape == (world, 2) and int(out['blocks'][:, 1].sum()) == case['H']
+    assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
+    if trend is not None:
+        assert np.array_equal(out['trend'], trend)
+
+
+def test_row_blocks():
+    from fib_tf_amd.sharded import row_blocks
+    assert row_blocks(512, 8) == [(64 * i, 64) for i in range(8)]
+    assert row_blocks(10, 3) == [(0, 4), (4, 3), (7, 3)]
+    b = row_blocks(4099, 8)
+    assert sum(n for _, n in b) == 4099 and all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(7))
+
+
+def test_thin_blocks_rejected(tmp_path):
+    """a halo deeper than a row block cannot be served by the nearest neighbour alone"""
+    case = {'model': 'fenton', 'H': 16, 'W': 16, 'diff': 1.5, 'hole': (8, 8, 2), 'ticks': 1, 's2': 9, 'amp': 1.0}
+    from sharded_worker import run_case
+    ctx = mp.get_context('spawn')
+    port = free_port()
+    procs = [ctx.Process(target=run_case, args=(r, 2, port, case, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode not in (0, None) for p in procs)      # ValueError on every rank
