@@ -1,0 +1,151 @@
+"""not-gpu: host logic of the Python API and the C-ABI surface (no compute calls)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'fibhip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(fibhip_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fib_tf_amd import _lib
+    assert os.path.exists(_lib.SO), 'run __graft_entry__.build() first'
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.SO]).decode()
+    exported = set(re.findall(r' T (fibhip_[a-z_0-9]+)', out))
+    assert set(syms) <= exported, sorted(set(syms) - exported)
+    L = _lib.lib()                                  # loads; binds every symbol with its signature
+    assert set(_lib.SYMBOLS) == set(syms)
+    assert L.fibhip_abi_version() == 1
+    assert [L.fibhip_nvar(m) for m in (0, 1, 2)] == [4, 8, 21]
+    assert [L.fibhip_default_steps_per_tick(m) for m in (0, 1, 2)] == [10, 5, 1]
+    assert L.fibhip_nvar(7) < 0 and b'unknown model' in L.fibhip_last_error()
+
+
+def test_desc_layout_matches_header():
+    """ctypes mirror of fibhip_desc: field order/types must follow include/fibhip.h"""
+    from fib_tf_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'fibhip.h')).read()
+    body = re.search(r'typedef struct fibhip_desc \{(.*?)\} fibhip_desc;', src, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(','):
+            names.append(re.sub(r'[\*\[\]0-9]', '', part.strip().split()[-1]))
+    assert names == [n for n, _ in _lib.Desc._fields_]
+
+
+def test_no_device_fails_loudly():
+    """in the GPU-less build container create() must raise, never fall back"""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.fenton import Fenton4v
+    if _lib.lib().fibhip_device_count() > 0:
+        pytest.skip('a HIP device is present')
+    m = Fenton4v({'height': 16, 'width': 16, 'dt': 0.1, 'diff': 1.0, 'duration': 1, 'dt_per_plot': 10})
+    with pytest.raises(_lib.FibhipError, match='no HIP device'):
+        m.define()
+    with pytest.raises(_lib.FibhipError, match='no HIP device'):
+        m.laplace(np.zeros((8, 8), np.float32))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'fib_tf_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.hpp', '.h')):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in txt and 'fib_oracle' not in txt and 'from oracle' not in txt, fn
+
+
+def test_config_and_api_semantics():
+    from fib_tf_amd.fenton import Fenton4v
+    from fib_tf_amd.br import BeelerReuter
+    from fib_tf_amd.court import Courtemanche
+    cfg = {'width': 512, 'height': 512, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.5, 'duration': 1000,
+           'timeline': False, 'timeline_name': 't.json', 'save_graph': True, 'my_key': 42}
+    m = Fenton4v(cfg)
+    assert m.my_key == 42 and m.width == 512 and m.phase is None and not m.defined      # ionic.py:35-42
+    assert (m.min_v, m.max_v, m.depol) == (0.0, 1.0, 0.0)
+    assert m.dt_per_step == 1
+    with pytest.raises(AssertionError):
+        m.add_pace_op('s2', 'luq', 1.0)                                                # ionic.py:141-142
+    m.dt_per_step = 10
+    assert m.millisecond_to_step(210) == 210 and m.millisecond_to_step(10) == 10       # fenton.py:176-177
+    b = BeelerReuter(dict(cfg, cheby=True, skip=False))
+    assert (b.min_v, b.max_v, b.depol) == (-90.0, 30.0, -84.6) and b.ab_coef.shape == (12, 7)
+    assert b.ab_coef.dtype == np.float32 and b.ab_coef[8, 0] == np.float32(2 * 0.095)
+    b.dt_per_step = 5
+    assert b.millisecond_to_step(300) == 600                                           # br.py:371
+    c = Courtemanche(cfg)
+    assert (c.min_v, c.max_v, c.depol, c.chronic) == (-100.0, 50.0, -81.0, True)
+    assert c.fast_states == ['V', '_Na_i_', '_m_', '_h_'] and len(c.VAR_NAMES) == 21
+    assert c.jit_scope() is c
+    with c as ctx:
+        assert ctx is c
+    m.defined = True
+    with pytest.raises(AssertionError):
+        m.add_hole_to_phase_field(256, 256, 30)                                        # ionic.py:92-93
+
+
+def test_pace_rectangles():
+    from fib_tf_amd.ionic import IonicModel
+    m = IonicModel({'height': 23, 'width': 31})
+    H, W = 23, 31
+    ref = {'left': np.s_[:, :5], 'right': np.s_[:, -5:], 'top': np.s_[:5, :], 'bottom': np.s_[-5:, :],
+           'luq': np.s_[1:H // 2, 1:W // 2], 'llq': np.s_[H // 2:-1, 1:W // 2],
+           'ruq': np.s_[1:H // 2, W // 2:-1], 'rlq': np.s_[H // 2:-1, W // 2:-1]}           # ionic.py:145-160
+    for loc, sl in ref.items():
+        a = np.zeros((H, W), bool)
+        a[sl] = True
+        r0, r1, c0, c1 = m.pace_rect(loc)
+        b = np.zeros((H, W), bool)
+        b[r0:r1, c0:c1] = True
+        assert np.array_equal(a, b), loc
+    assert m.pace_rect('elsewhere') is None
+
+
+def test_phase_field_and_chebyshev_host_side(golden):
+    from fib_tf_amd.ionic import IonicModel
+    from fib_tf_amd.br import BeelerReuter
+    u = golden('unit_ops')
+    m = IonicModel({'height': 37, 'width': 53})
+    m.add_hole_to_phase_field(20, 15, 6)
+    assert np.array_equal(m.phase, u['hole_a']) and m.phase.dtype == np.float32
+    m.add_hole_to_phase_field(26, 18, 30, neg=True)
+    assert np.array_equal(m.phase, u['hole_ab'])
+    g = golden('br_cheby_table')
+    b = BeelerReuter({'height': 8, 'width': 8, 'cheby': True})
+    v, al, be = b.calc_alpha_beta_np()
+    assert np.array_equal(v, g['v']) and np.array_equal(al, g['alpha']) and np.array_equal(be, g['beta'])
+    assert np.array_equal(b.chebyshev_table(), g['d'])          # bit-identical to the reference's `d` (br.py:327)
+    # the fitted h_tau goes negative on part of the range — intended behaviour to reproduce
+    x = (np.linspace(-90, 30, 241) + 30.0) / 60.0
+    S = [np.ones_like(x), x]
+    for _ in range(7):
+        S.append(2 * x * S[-1])
+    h_tau = sum(d * s for d, s in zip(g['d'][3], S))
+    assert h_tau.min() < -1.0
+
+
+def test_bench_cli_contract():
+    import bench
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for key in ('"roofline"', "'roofline'"):
+        if key in src:
+            break
+    else:
+        pytest.fail('bench.py must emit a roofline object')
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in src
+    assert bench.ALGO_BYTES['fenton'] + 4 == 36 and bench.ALGO_BYTES['br'] + 4 == 68
