@@ -42,7 +42,7 @@ def make_model(args, height=None, device=0):
     H = height or S
     sc = S / 512.0
     base = {'width': S, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'timeline': False,
-            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': args.fast}
+            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not args.exact}
     if args.model == 'fenton':                        # fenton.py:156-171
         m = Fenton4v(dict(base, diff=1.5))
         m.add_hole_to_phase_field(256 * sc, H / 2.0, 30 * sc)
@@ -161,7 +161,7 @@ def bench_single(args):
                                '1 step = 1 run() tick = %d sub-steps' % (
                                    args.model, m.height, m.width, {'fenton': 1, 'br': 2, 'court': 4}[args.model], spt),
                    'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
-                   'arithmetic': 'fast' if args.fast else 'exact (one rounding per reference op)',
+                   'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
                    'parallelism': 'single device'},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
@@ -183,7 +183,7 @@ def main():
     ap.add_argument('--model', default='fenton', choices=['fenton', 'br', 'court'])
     ap.add_argument('--size', type=int, default=0, help='grid width (and height at N=1); default 512 (1024 court)')
     ap.add_argument('--rows-per-gpu', type=int, default=512)
-    ap.add_argument('--fast', action='store_true', help='FIBHIP_FAST arithmetic policy')
+    ap.add_argument('--exact', action='store_true', help="config['fast_math']=False: one rounding per reference op")
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')

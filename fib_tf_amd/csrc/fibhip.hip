@@ -75,6 +75,26 @@ static hipError_t launch_tick(hipStream_t st, const LaunchCtx &c)
     return hipGetLastError();
 }
 
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+static hipError_t launch_strip(hipStream_t st, const LaunchCtx &c)
+{
+    Geo g = c.g;
+    g.tiles_x = (g.W + TX - 1) / TX;
+    const int tiles_y = (g.r1 - g.r0 + TY - 1) / TY;
+    g.ntiles = g.tiles_x * tiles_y;
+    if (g.ntiles <= 0) return hipSuccess;
+    PtrTab<M::NVAR> pt;
+    for (int v = 0; v < M::NVAR; ++v) {
+        pt.in[v] = c.in[v];
+        pt.out[v] = c.out[v];
+    }
+    constexpr int NT = 64 * ((TY + 2 * (K - 1) + R - 1) / R);
+    const int grid = ((g.ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((strip_kernel<M, P, MODE, K, TX, TY, R, PHASE>), dim3(grid), dim3(NT), 0, st, g, pt, c.ph,
+                       *static_cast<const typename M::Consts *>(c.consts), c.sub0);
+    return hipGetLastError();
+}
+
 template <class M, class P, int MODE>
 static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
 {
@@ -103,11 +123,27 @@ struct Variant {
     {MID, MODE, 1, 0, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, false>},        \
     {MID, MODE, 1, 1, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, true>}
 
+// strip kernels are listed with NT = -R (rows per wave)
+#define S4(MODEL, MID, MODE, K, TX, TY, R)                                                         \
+    {MID, MODE, 0, 0, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, false>},     \
+    {MID, MODE, 0, 1, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, true>},      \
+    {MID, MODE, 1, 0, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, false>},      \
+    {MID, MODE, 1, 1, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, true>}
+
 // The first matching entry with the wanted K is the default; FIBHIP_VARIANT="K,TX,TY,NT" overrides
 // (tuning sweeps).  Tile shapes: K=1 tiles are wide (coalesced 256-B rows); K>1 tiles are square-ish
 // to keep the redundant rim small.
 static const Variant g_variants[] = {
     // ---- Fenton 4v ----
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 6),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 32, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 2, 60, 18, 4),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 512),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 1024),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 256),
@@ -119,10 +155,18 @@ static const Variant g_variants[] = {
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 4, 256),
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
+    S4(BeelerReuter, FIBHIP_BR, 0, 3, 58, 19, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 18, 2),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
+    S4(BeelerReuter, FIBHIP_BR, 1, 3, 58, 19, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 18, 2),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 512),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 16, 256),
@@ -151,7 +195,7 @@ struct fibhip_ctx {
     bool own_s0;
     float *slab[2];
     bool own_slab;
-    float *phase3;          // dpy | dpx | q4, each `cells` floats
+    float *phase3;          // dpy | dpx | q4 | r4, each `cells` floats
     float *phi_dev;
     bool has_phase;
     int cur[21];            // which slab holds variable v
@@ -233,7 +277,16 @@ static int build_plan(fibhip_ctx *h)
     }
     if (!prefK)
         if (const char *e = getenv("FIBHIP_K")) prefK = atoi(e);
-    if (!prefK) prefK = (h->d.model == FIBHIP_COURT) ? 1 : 5;
+    if (!prefK) {
+        // measured on MI355X (tuning table): a grid that gives each CU about one tile is
+        // launch/latency-bound and wants the deepest fusion; a grid with many tiles per CU is
+        // throughput-bound and wants the smaller redundant rim of a shallower one
+        const bool small = h->cells <= (size_t)1 << 20;
+        // Beeler-Reuter / Courtemanche spend their time in the transcendental pipe (64 / ~70 per
+        // cell-step), so redundant rim cells cost more than the launches they save: one sub-step
+        // per launch.  Fenton is cheap per cell: fuse.
+        prefK = (h->d.model != FIBHIP_FENTON4V) ? 1 : (small ? 10 : 5);
+    }
     const int maxghost = (h->d.ghost_top > 0 || h->d.ghost_bottom > 0)
                              ? (h->d.ghost_top > 0 && h->d.ghost_bottom > 0
                                     ? (h->d.ghost_top < h->d.ghost_bottom ? h->d.ghost_top : h->d.ghost_bottom)
@@ -353,7 +406,7 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
         }
         h->own_slab = true;
     }
-    HIPCHK(hipMalloc((void **)&h->phase3, 3 * h->cells * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&h->phase3, 4 * h->cells * sizeof(float)));
     HIPCHK(hipMalloc((void **)&h->phi_dev, h->cells * sizeof(float)));
     HIPCHK(hipHostMalloc((void **)&h->probe_host, 64, hipHostMallocDefault));
     h->has_phase = false;
@@ -422,7 +475,7 @@ extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
     HIPCHK(hipMemcpyAsync(h->phi_dev, phi, h->cells * sizeof(float), hipMemcpyHostToDevice, h->s0));
     const Geo g = base_geo(h);
     hipLaunchKernelGGL(phase_prep_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->phi_dev, h->phase3,
-                       h->phase3 + h->cells, h->phase3 + 2 * h->cells);
+                       h->phase3 + h->cells, h->phase3 + 2 * h->cells, h->phase3 + 3 * h->cells);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->s0));          // `phi` may be a temporary of the caller
     h->has_phase = true;
@@ -488,6 +541,7 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     c.ph.dpy = h->phase3;
     c.ph.dpx = h->phase3 + h->cells;
     c.ph.q4 = h->phase3 + 2 * h->cells;
+    c.ph.r4 = h->phase3 + 3 * h->cells;
     c.consts = consts_of(h);
 }
 
@@ -704,8 +758,8 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
     HIPCHK(hipSetDevice(device));
     const size_t n = (size_t)H * W, B = n * sizeof(float);
     float *d = nullptr;
-    HIPCHK(hipMalloc((void **)&d, 8 * B));          // a b c phi ph3[3] out
-    float *da = d, *db = d + n, *dc = d + 2 * n, *dphi = d + 3 * n, *dph3 = d + 4 * n, *dout = d + 7 * n;
+    HIPCHK(hipMalloc((void **)&d, 9 * B));          // a b c phi ph3[4] out
+    float *da = d, *db = d + n, *dc = d + 2 * n, *dphi = d + 3 * n, *dph3 = d + 4 * n, *dout = d + 8 * n;
     int rc = 0;
     do {
         if (hipMemcpy(da, a, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
@@ -715,7 +769,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
             g.H = g.Hg = H; g.W = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.tiles_x = g.ntiles = 0;
-            hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n);
+            hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
         }
         const float mdt = (float)(-dt);
         if (fast)

@@ -43,6 +43,7 @@ struct PhaseTab {    // derived from ϕ once at set_phase (ionic.py:78-80)
     const float *dpy;   // ϕ[r+1,c] - ϕ[r-1,c]   (REFLECT-padded)
     const float *dpx;   // ϕ[r,c+1] - ϕ[r,c-1]
     const float *q4;    // 4 * ϕ[r,c]
+    const float *r4;    // RN(1 / q4): lets the division by 4ϕ run as a 3-instruction exact form
 };
 
 enum : unsigned {
@@ -61,10 +62,12 @@ static FIB_DEV float stencil9(float N, float S, float Wv, float E, float NW, flo
     return l - 6.0f * C;
 }
 // phase-field correction, ionic.py:78-80, from the pre-differenced ϕ terms
+// (the division is always the correctly rounded form: the Laplacian incl. its phase term is pure
+// arithmetic and stays bit-identical to the reference under both arithmetic policies)
 template <class P>
-static FIB_DEV float phase_term(float N, float S, float Wv, float E, float dpy, float dpx, float q4)
+static FIB_DEV float phase_term(float N, float S, float Wv, float E, float dpy, float dpx, float q4, float r4)
 {
-    return P::div((S - N) * dpy + (E - Wv) * dpx, q4);
+    return Exact::divc((S - N) * dpy + (E - Wv) * dpx, q4, r4);
 }
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous run of tiles so
@@ -107,7 +110,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
 
     // ---- per-cell registers -------------------------------------------------------------------
     float s[CPT][NV];
-    float pdy[CPT], pdx[CPT], pq4[CPT];
+    float pdy[CPT], pdx[CPT], pq4[CPT], pr4[CPT];
     int li[CPT], off[CPT];
     unsigned fl[CPT];
 #pragma unroll
@@ -126,6 +129,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
             pdy[j] = ph.dpy[off[j]];
             pdx[j] = ph.dpx[off[j]];
             pq4[j] = ph.q4[off[j]];
+            pr4[j] = ph.r4[off[j]];
         }
         const bool border = gyg == 0 || gyg == g.Hg - 1 || gx == 0 || gx == g.W - 1;
         unsigned f = 0;
@@ -157,7 +161,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float NW = A[i - LP - 1], SW = A[i + LP - 1], NE = A[i - LP + 1], SE = A[i + LP + 1];
                 const float C = A[i];
                 float l = stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
-                if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j]);   // ionic.py:58
+                if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
                 M::template step<P, MODE>(s[j], C, l, k, sub0 + st);
             }
         }
@@ -205,6 +209,198 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 if ((WMASK >> v) & 1u) pt.out[v][off[j]] = s[j][v];
         }
     }
+}
+
+
+#ifdef FIB_STAMPS   // diagnostic build only (tools/ubench/stamp_strip.hip): per-wave s_memtime stamps
+__device__ unsigned long long fib_stamps[4096 * 16];
+#define FIB_STAMP(slot)                                                                          \
+    do {                                                                                         \
+        if ((threadIdx.x & 63) == 0 && (slot) < 16)                                              \
+            fib_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FIB_STAMP(slot) do { } while (0)
+#endif
+
+// strip_kernel<M,P,MODE,K,TX,TY,R,PHASE> — the K > 1 workhorse.
+//   Same temporal blocking as tick_kernel, different work layout: the LDS tile is exactly 64 words
+//   wide (compute box CX = TX + 2(K-1) <= 62 plus the two ring columns), lane l of every wave owns
+//   column l, and wave w owns the R consecutive rows [wR, wR+R) of the compute box.  Consequences:
+//     * every LDS access of a wave is 64 consecutive words: conflict-free, and a thread reads the
+//       3 x (R+2) window of its R cells once per sub-step (3(R+2)/R instead of 9 reads per cell);
+//     * rows are wave-uniform, so the rows that have gone stale (one more ring per sub-step) are
+//       skipped with scalar branches — the box shrinks in y as the sub-steps proceed;
+//     * the vertical border/ghost refresh is wave-uniform too; only the two edge columns need a
+//       per-lane predicate.
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+__global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
+strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0)
+{
+    constexpr int NV = M::NVAR;
+    constexpr int CX = TX + 2 * (K - 1), CY = TY + 2 * (K - 1);
+    static_assert(CX <= 62 && K > 1, "strip_kernel: compute box must fit 62 lanes");
+    constexpr int NW = (CY + R - 1) / R;
+    constexpr int LP = 64, LQ = NW * R + 2, NL = LP * LQ;
+    constexpr unsigned WMASK = M::mask(MODE);
+    __shared__ float lds[2][NL];
+
+    const int tile = xcd_tile(blockIdx.x, g.ntiles);
+    if (tile >= g.ntiles) return;
+    FIB_STAMP(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
+    const int x0 = bx * TX, y0 = g.r0 + by * TY;
+    const int cx0 = x0 - (K - 1), cy0 = y0 - (K - 1);
+    const int gx = cx0 - 1 + lane;                                  // this lane's global column
+    const int xx = clampi(gx, 1, g.W - 2);
+
+    // ---- potential tile through the boundary clamp: one coalesced row per wave-iteration.  All
+    // global loads of the prologue (tile rows here, per-cell state below) are issued before the first
+    // LDS write waits on any of them: one memory latency instead of one per row.
+    const float *vin = pt.in[0];
+    constexpr int NF = (LQ + NW - 1) / NW;
+    float fv[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int row = min(wave + q * NW, LQ - 1);
+        int yy = clampi(cy0 - 1 + row + g.row_off, 1, g.Hg - 2) - g.row_off;
+        yy = clampi(yy, 0, g.H - 1);
+        fv[q] = vin[(size_t)yy * g.W + xx];
+    }
+
+    // ---- per-cell registers ---------------------------------------------------------------------
+    const int la = min(max(lane, 1), 62);                           // keeps every tap of an idle lane in bounds
+    const bool lane_in = lane >= 1 && lane <= CX && gx >= 0 && gx < g.W;
+    const bool col_border = gx == 0 || gx == g.W - 1;
+    const bool left = gx == 1, right = gx == g.W - 2;               // refresh col 0 / W-1 (+ ghost)
+    const bool left2 = left && lane >= 2, right2 = right && lane <= 61;
+    const bool edge_tile_h = (cx0 <= 1) || (cx0 + CX >= g.W - 1);   // block-uniform
+    const bool store_col = lane_in && gx >= x0 && gx < x0 + TX;
+    float s[R][NV], pdy[R], pdx[R], pq4[R], pr4[R];
+    int off[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = cy0 + wave * R + r;
+        off[r] = clampi(gy, 0, g.H - 1) * g.W + clampi(gx, 0, g.W - 1);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
+        if (PHASE) {
+            pdy[r] = ph.dpy[off[r]];
+            pdx[r] = ph.dpx[off[r]];
+            pq4[r] = ph.q4[off[r]];
+            pr4[r] = ph.r4[off[r]];
+        }
+    }
+    // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
+    // the box reaches the domain edge on that side (no staleness enters through a real boundary)
+    const bool top_open = cy0 + g.row_off > 0, bot_open = cy0 + CY + g.row_off < g.Hg;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int row = wave + q * NW;
+        if (row < LQ) {
+            lds[0][row * LP + lane] = fv[q];
+            lds[1][row * LP + lane] = fv[q];
+        }
+    }
+    FIB_STAMP(1);
+    __syncthreads();
+    FIB_STAMP(2);
+
+#pragma unroll 1
+    for (int st = 0; st < K; ++st) {
+        const float *A = lds[st & 1];
+        float *B = lds[(st & 1) ^ 1];
+        const int need0 = top_open ? st : 0, need1 = bot_open ? CY - st : CY;
+        // rows [ra, rb) of this wave's strip are live at this sub-step (wave-uniform)
+        const int c0 = wave * R;
+        int ra = max(0, need0 - c0), rb = min(R, need1 - c0);
+        ra = max(ra, -(cy0 + c0 + g.row_off));                      // global row >= 0
+        rb = min(rb, min(g.Hg - g.row_off, g.H) - (cy0 + c0));      // global row < Hg, local row < H
+        ra = max(ra, -(cy0 + c0));                                  // local row >= 0
+        if (ra == 0 && rb == R) {
+            // ---- whole strip live: one straight-line block.  The R cells of a lane are independent,
+            // so the scheduler can interleave their dependency chains; the 3 x (R+2) window is read once.
+            float win[R + 2][3];
+#pragma unroll
+            for (int q = 0; q < R + 2; ++q) {
+                const int i = (c0 + q) * LP + la;
+                win[q][0] = A[i - 1];
+                win[q][1] = A[i];
+                win[q][2] = A[i + 1];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float l = stencil9(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
+                                   win[r][2], win[r + 2][2], win[r + 1][1]);
+                if (PHASE)
+                    l = l + phase_term<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r], pq4[r],
+                                          pr4[r]);
+                M::template step<P, MODE>(s[r], win[r + 1][1], l, k, sub0 + st);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r >= ra && r < rb) {                            // scalar branch
+                    const int i = (c0 + r + 1) * LP + la;
+                    const float NW_ = A[i - LP - 1], N = A[i - LP], NE = A[i - LP + 1];
+                    const float Wv = A[i - 1], C = A[i], E = A[i + 1];
+                    const float SW = A[i + LP - 1], S = A[i + LP], SE = A[i + LP + 1];
+                    float l = stencil9(N, S, Wv, E, NW_, SW, NE, SE, C);
+                    if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[r], pdx[r], pq4[r], pr4[r]);
+                    M::template step<P, MODE>(s[r], C, l, k, sub0 + st);
+                }
+            }
+        }
+        // ---- publish the new potential for the next sub-step --------------------------------------
+        if (st + 1 < K) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int cyy = c0 + r;
+                const int gyg = cy0 + cyy + g.row_off;
+                if (r >= ra && r < rb && gyg != 0 && gyg != g.Hg - 1) {     // wave-uniform
+                    const int i = (cyy + 1) * LP + la;
+                    const float u = s[r][0];
+                    const bool w = lane_in && !col_border;
+                    // own row, plus the border/ghost copies above/below (enforce_boundary + REFLECT);
+                    // the column copies ride along, which also covers the four domain corners
+                    auto put = [&](int o) {
+                        if (w) B[o] = u;
+                        if (edge_tile_h) {
+                            if (w && left) B[o - 1] = u;
+                            if (w && left2) B[o - 2] = u;
+                            if (w && right) B[o + 1] = u;
+                            if (w && right2) B[o + 2] = u;
+                        }
+                    };
+                    put(i);
+                    if (gyg == 1) {
+                        put(i - LP);
+                        if (cyy >= 1) put(i - 2 * LP);
+                    }
+                    if (gyg == g.Hg - 2) {
+                        put(i + LP);
+                        if (cyy + 1 < LQ - 2) put(i + 2 * LP);
+                    }
+                }
+            }
+        }
+        if (st + 1 < K) __syncthreads();
+        FIB_STAMP(3 + st);
+    }
+
+    // ---- write back ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = cy0 + wave * R + r;
+        if (store_col && gy >= y0 && gy < min(y0 + TY, g.r1) && gy < g.H) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if ((WMASK >> v) & 1u) pt.out[v][off[r]] = s[r][v];
+        }
+    }
+    FIB_STAMP(14);
 }
 
 // Pointwise re-evaluation without the stencil: Courtemanche's 'slow' op (court.py:103,615-617).
@@ -256,7 +452,7 @@ __global__ void unit_op_kernel(int op, int H, int W, const float *a, const float
             if (op == OP_LAPLACE)
                 r = stencil9(N, S, Wv, E, a[yn * W + xw], a[ys * W + xw], a[yn * W + xe], a[ys * W + xe], a[e]);
             if (ph3) {
-                const float f = phase_term<P>(N, S, Wv, E, ph3[e], ph3[n + e], ph3[2 * n + e]);
+                const float f = phase_term<P>(N, S, Wv, E, ph3[e], ph3[n + e], ph3[2 * n + e], ph3[3 * n + e]);
                 r = (op == OP_LAPLACE) ? r + f : f;
             }
             out[e] = r;
@@ -265,7 +461,7 @@ __global__ void unit_op_kernel(int op, int H, int W, const float *a, const float
 }
 
 // ϕ -> (dpy, dpx, q4), REFLECT-padded in GLOBAL coordinates (ionic.py:75-80)
-__global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dpx, float *q4)
+__global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dpx, float *q4, float *r4)
 {
     const int n = g.H * g.W;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
@@ -280,6 +476,7 @@ __global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dp
         dpy[e] = phi[ys * g.W + x] - phi[yn * g.W + x];
         dpx[e] = phi[y * g.W + xe] - phi[y * g.W + xw];
         q4[e] = 4.0f * phi[e];
+        r4[e] = 1.0f / q4[e];                       // IEEE division: correctly rounded reciprocal
     }
 }
 

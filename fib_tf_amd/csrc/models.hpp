@@ -24,7 +24,19 @@ namespace fib {
 
 #define FIB_DEV __device__ __forceinline__
 
+// Division by a value whose correctly rounded reciprocal rc = RN(1/c) is known (a compile-time
+// constant, or the per-cell 1/(4ϕ) prepared once): q = RN(a*rc); r = a - q*c (exact, one FMA);
+// RN(q + r*rc) is the correctly rounded quotient RN(a/c) (Markstein's theorem) — bit-identical to
+// IEEE division at 3 instructions instead of the ~11 of the generic expansion.  Checked exhaustively
+// over all 2^23 significands for every constant of the three models (tools/ubench/divtest.c);
+// it can differ only when a/c is subnormal (by at most one subnormal ulp).
 struct Exact {
+    static FIB_DEV float divc(float a, float c, float rc)
+    {
+        const float q = a * rc;
+        const float r = __builtin_fmaf(-q, c, a);
+        return __builtin_fmaf(r, rc, q);
+    }
     static FIB_DEV float div(float a, float b) { return a / b; }
     static FIB_DEV float rcp(float a) { return 1.0f / a; }
     static FIB_DEV float exp(float a) { return expf(a); }
@@ -35,6 +47,7 @@ struct Exact {
 };
 
 struct Fast {
+    static FIB_DEV float divc(float a, float, float rc) { return a * rc; }
     static FIB_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
     static FIB_DEV float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
     static FIB_DEV float exp(float a) { return __expf(a); }
@@ -65,6 +78,8 @@ static FIB_DEV float rush_larsen_c(float g, float ginf, float em1)
 }
 
 #define FC(x) ((float)(x))
+// x / (float constant c), through the constant's correctly rounded reciprocal
+#define DC(x, c) P::divc((x), FC(c), 1.0f / FC(c))
 
 // =====================================================================================
 // Fenton 4v  (fenton.py:46-108)
@@ -83,11 +98,10 @@ struct Fenton {
     static FIB_DEV void step(float (&s)[NVAR], float U0, float lap, const Consts &k, int)
     {
         // constants fenton.py:49-71
-        constexpr float tau_vp = FC(3.33), tau_vn = FC(19.2), tau_wp = FC(160.0), tau_wn1 = FC(75.0),
-                        tau_wn2 = FC(75.0), tau_d = FC(0.065), tau_si = FC(31.8364), tau_so = FC(31.8364),
-                        tau_a = FC(0.009), u_c = FC(0.23), u_w = FC(0.146), u_0 = FC(0.0), u_m = FC(1.0),
-                        u_csi = FC(0.8), u_so = FC(0.3), r_sn = FC(1.2), k_ = FC(3.0), b_so = FC(0.84),
-                        c_so = FC(0.02);
+        // divisors appear literally below: tau_d 0.065, tau_si = tau_so 31.8364, c_so 0.02, tau_vp 3.33,
+        // tau_vn 19.2, tau_wp 160, tau_wn1 = tau_wn2 75
+        constexpr float tau_a = FC(0.009), u_c = FC(0.23), u_w = FC(0.146), u_0 = FC(0.0), u_m = FC(1.0),
+                        u_csi = FC(0.8), u_so = FC(0.3), r_sn = FC(1.2), k_ = FC(3.0), b_so = FC(0.84);
         constexpr float half_aso = FC(0.5 * (0.115 - 0.009));   // 0.5*(a_so - tau_a) in double
         constexpr float rsp_m_rsn = FC(0.02 - 1.2);             // (r_sp - r_sn) in double
         const float U = s[0], V = s[1], W = s[2], S = s[3];     // raw U: fenton.py:101
@@ -96,14 +110,14 @@ struct Fenton {
         const float Huso = (1.0f + sgnf(U - u_so)) * 0.5f;
         const float Guso = (1.0f - sgnf(U - u_so)) * 0.5f;      // G(), :77-79
 
-        const float I_fi = P::div((((-V) * Huc) * (U - u_c)) * (u_m - U), tau_d);                // :81
-        const float I_si = P::div((-W) * S, tau_si);                                             // :82
-        const float I_so = (half_aso * (1.0f + P::tanh(P::div(U - b_so, c_so))) +
-                            P::div((U - u_0) * Guso, tau_so)) + Huso * tau_a;                    // :83-84
+        const float I_fi = DC((((-V) * Huc) * (U - u_c)) * (u_m - U), 0.065);                // :81
+        const float I_si = DC((-W) * S, 31.8364);                                             // :82
+        const float I_so = (half_aso * (1.0f + P::tanh(DC(U - b_so, 0.02))) +
+                            DC((U - u_0) * Guso, 31.8364)) + Huso * tau_a;                    // :83-84
         const float dU = -((I_fi + I_si) + I_so);                                                // :86
-        const float dV = (U > u_c) ? P::div(-V, tau_vp) : P::div(1.0f - V, tau_vn);              // :87
-        const float dW = (U > u_c) ? P::div(-W, tau_wp)
-                                   : ((U > u_w) ? P::div(1.0f - W, tau_wn2) : P::div(1.0f - W, tau_wn1)); // :88
+        const float dV = (U > u_c) ? DC(-V, 3.33) : DC(1.0f - V, 19.2);              // :87
+        const float dW = (U > u_c) ? DC(-W, 160.0)
+                                   : ((U > u_w) ? DC(1.0f - W, 75.0) : DC(1.0f - W, 75.0)); // :88
         const float r_s = rsp_m_rsn * Huc + r_sn;                                                // :89
         const float dS = r_s * (0.5f * (1.0f + P::tanh((U - u_csi) * k_)) - S);                  // :90
 
@@ -166,7 +180,8 @@ struct BeelerReuter {
         if (MODE == MODE_CHEBY) {                                   // br.py:207-252
             constexpr float xmid = FC(0.5 * (30.0 + -90.0)), xhalf = FC(0.5 * (30.0 - -90.0));
             float S[9];
-            const float x = P::div(V0 - xmid, xhalf);               // :215
+            // always the correctly rounded quotient: the degree-8 sums amplify an ulp of x by ~1e2
+            const float x = Exact::divc(V0 - xmid, xhalf, 1.0f / xhalf);           // :215
             S[0] = 1.0f; S[1] = x;                                  // calc_chebyshev_leading :289-301
 #pragma unroll
             for (int i = 2; i <= 8; ++i) S[i] = (2.0f * x) * S[i - 1];
@@ -211,7 +226,7 @@ struct BeelerReuter {
         const float ECa = FC(0.0 - 82.3) - 13.0278f * P::log(C);
         const float iCa = ((FC(1.0 * 0.09) * D) * F) * (V0 - ECa);
         const float I_sum = ((iK1 + ix1) + iNa) + iCa;
-        const float V1 = clipf((V0 + k.ddt * lap) - P::div(k.dt * I_sum, 1.0f), -85.0f, 25.0f);   // :167-168
+        const float V1 = clipf((V0 + k.ddt * lap) - (k.dt * I_sum), -85.0f, 25.0f);   // :167-168
         const float dC = -1.0e-7f * iCa + 0.07f * (1.0e-7f - C);                                   // :170
         s[0] = V1;
         s[1] = C + k.dt * dC;
@@ -260,16 +275,16 @@ struct Courtemanche {
                          sigma = 1.0;
         constexpr float RT = FC(R * T);
         const float eps = V * FC(1e-20);                                                          // :298
-        o.d_inf = P::rcp(1.0f + P::exp(P::div(V + 10.0f, -8.0f)));                                // :300
+        o.d_inf = P::rcp(1.0f + P::exp(P::divc(V + 10.0f, -8.0f, 1.0f / (-8.0f))));                                // :300
         {                                                                                          // :303-307
             const float a = P::div(4.579f, 1.0f + P::exp(P::div(V + 10.0f, FC(-6.24))));
             const float vp = V + FC(10.0001);
-            const float e = P::exp(P::div(vp, FC(-6.24)));
+            const float e = P::exp(P::divc(vp, FC(-6.24), 1.0f / (FC(-6.24))));
             const float b = P::div(1.0f - e, (FC(0.0350000) * vp) * (1.0f + e));
             o.tau_d = (fabsf(vp) < FC(1.0e-10)) ? a : b;
         }
         {                                                                                          // :309
-            const float e = P::exp(P::div(-(V + 28.0f), FC(6.9)));
+            const float e = P::exp(P::divc(-(V + 28.0f), FC(6.9), 1.0f / (FC(6.9))));
             o.f_inf = P::div(e, 1.0f + e);
         }
         {                                                                                          // :310
@@ -279,24 +294,24 @@ struct Courtemanche {
         }
         {                                                                                          // :312-316
             const float vm = V - FC(7.9);
-            const float e = P::exp(P::div(-vm, 5.0f));
+            const float e = P::exp(P::divc(-vm, 5.0f, 1.0f / (5.0f)));
             const float b = P::div(6.0f * (1.0f - e), ((1.0f + FC(0.3) * e) * 1.0f) * vm);
             o.tau_w = (fabsf(vm) < FC(1.0e-10)) ? eps + FC((6.0 * 0.2) / 1.3) : b;
         }
-        o.w_inf = 1.0f - P::rcp(1.0f + P::exp(P::div(-(V - 40.0f), 17.0f)));                      // :318
+        o.w_inf = 1.0f - P::rcp(1.0f + P::exp(P::divc(-(V - 40.0f), 17.0f, 1.0f / (17.0f))));                      // :318
         float al, be;
         {                                                                                          // :320-329
             const float vp = V - FC(-47.13), vq = V + FC(47.13);
             al = (fabsf(vp) < FC(0.001)) ? eps + FC(3.2) : P::div(FC(0.32) * vq, 1.0f - P::exp(FC(-0.1) * vq));
-            be = FC(0.08) * P::exp(P::div(-V, 11.0f));
+            be = FC(0.08) * P::exp(P::divc(-V, 11.0f, 1.0f / (11.0f)));
             o.m_inf = P::div(al, al + be);
             o.tau_m = P::rcp(al + be);
         }
         const bool lo = V < -40.0f;
         {                                                                                          // :331-344
-            al = lo ? FC(0.135) * P::exp(P::div(V + 80.0f, FC(-6.8))) : eps;
+            al = lo ? FC(0.135) * P::exp(P::divc(V + 80.0f, FC(-6.8), 1.0f / (FC(-6.8)))) : eps;
             be = lo ? FC(3.56) * P::exp(FC(0.079) * V) + 310000.0f * P::exp(FC(0.35) * V)
-                    : P::rcp(FC(0.13) * (1.0f + P::exp(P::div(V + FC(10.66), FC(-11.1)))));
+                    : P::rcp(FC(0.13) * (1.0f + P::exp(P::divc(V + FC(10.66), FC(-11.1), 1.0f / (FC(-11.1))))));
             o.h_inf = P::div(al, al + be);
             o.tau_h = P::rcp(al + be);
         }
@@ -312,24 +327,24 @@ struct Courtemanche {
         }
         const float v10 = V - -10.0f;
         {                                                                                          // :361-365, :373-377
-            al = FC(0.65) * P::rcp(P::exp(P::div(v10, -8.5f)) + P::exp(P::div(v10 - 40.0f, -59.0f)));
-            be = FC(0.65) * P::rcp(2.5f + P::exp(P::div(v10 + 72.0f, 17.0f)));
-            o.tau_oa = P::div(P::rcp(al + be), 3.0f);
+            al = FC(0.65) * P::rcp(P::exp(P::divc(v10, -8.5f, 1.0f / (-8.5f))) + P::exp(P::divc(v10 - 40.0f, -59.0f, 1.0f / (-59.0f))));
+            be = FC(0.65) * P::rcp(2.5f + P::exp(P::divc(v10 + 72.0f, 17.0f, 1.0f / (17.0f))));
+            o.tau_oa = P::divc(P::rcp(al + be), 3.0f, 1.0f / (3.0f));
             o.tau_ua = o.tau_oa;            // alpha_ua/beta_ua are the same expressions (:373-376)
-            o.oa_inf = P::rcp(1.0f + P::exp(P::div(v10 + FC(10.47), FC(-17.54))));
-            o.ua_inf = P::rcp(1.0f + P::exp(P::div(v10 + FC(20.3), FC(-9.6))));
+            o.oa_inf = P::rcp(1.0f + P::exp(P::divc(v10 + FC(10.47), FC(-17.54), 1.0f / (FC(-17.54)))));
+            o.ua_inf = P::rcp(1.0f + P::exp(P::divc(v10 + FC(20.3), FC(-9.6), 1.0f / (FC(-9.6)))));
         }
         {                                                                                          // :367-371
-            al = P::rcp(FC(18.53) + 1.0f * P::exp(P::div(v10 + FC(103.7), FC(10.95))));
-            be = P::rcp(FC(35.56) + 1.0f * P::exp(P::div(v10 - FC(8.74), FC(-7.44))));
-            o.tau_oi = P::div(P::rcp(al + be), 3.0f);
-            o.oi_inf = P::rcp(1.0f + P::exp(P::div(v10 + FC(33.1), FC(5.3))));
+            al = P::rcp(FC(18.53) + 1.0f * P::exp(P::divc(v10 + FC(103.7), FC(10.95), 1.0f / (FC(10.95)))));
+            be = P::rcp(FC(35.56) + 1.0f * P::exp(P::divc(v10 - FC(8.74), FC(-7.44), 1.0f / (FC(-7.44)))));
+            o.tau_oi = P::divc(P::rcp(al + be), 3.0f, 1.0f / (3.0f));
+            o.oi_inf = P::rcp(1.0f + P::exp(P::divc(v10 + FC(33.1), FC(5.3), 1.0f / (FC(5.3)))));
         }
         {                                                                                          // :379-383
-            al = P::rcp(21.0f + 1.0f * P::exp(P::div(v10 - 195.0f, -28.0f)));
-            be = P::rcp(P::exp(P::div(v10 - 168.0f, -16.0f)));
-            o.tau_ui = P::div(P::rcp(al + be), 3.0f);
-            o.ui_inf = P::rcp(1.0f + P::exp(P::div(v10 - FC(109.45), FC(27.48))));
+            al = P::rcp(21.0f + 1.0f * P::exp(P::divc(v10 - 195.0f, -28.0f, 1.0f / (-28.0f))));
+            be = P::rcp(P::exp(P::divc(v10 - 168.0f, -16.0f, 1.0f / (-16.0f))));
+            o.tau_ui = P::divc(P::rcp(al + be), 3.0f, 1.0f / (3.0f));
+            o.ui_inf = P::rcp(1.0f + P::exp(P::divc(v10 - FC(109.45), FC(27.48), 1.0f / (FC(27.48)))));
         }
         {                                                                                          // :385-398
             const float va = V + FC(14.1), vb = V - FC(3.3328);
@@ -338,7 +353,7 @@ struct Courtemanche {
             be = (fabsf(vb) < FC(1.0e-10)) ? eps + FC(0.000378361)
                                            : P::div(FC(7.3898e-05) * vb, P::exp(P::div(vb, FC(5.1237))) - 1.0f);
             o.tau_xr = P::rcp(al + be);
-            o.xr_inf = P::rcp(1.0f + P::exp(P::div(va, -6.5f)));
+            o.xr_inf = P::rcp(1.0f + P::exp(P::divc(va, -6.5f, 1.0f / (-6.5f))));
         }
         {                                                                                          // :400-413
             const float vs = V - FC(19.9);
@@ -346,13 +361,13 @@ struct Courtemanche {
             al = sing ? eps + FC(0.00068) : P::div(FC(4.0e-05) * vs, 1.0f - P::exp(P::div(vs, -17.0f)));
             be = sing ? eps + FC(0.000315) : P::div(FC(3.5e-05) * vs, P::exp(P::div(vs, 9.0f)) - 1.0f);
             o.tau_xs = 0.5f * P::rcp(al + be);
-            o.xs_inf = P::sqrt(P::rcp(1.0f + P::exp(P::div(vs, FC(-12.7)))));
+            o.xs_inf = P::sqrt(P::rcp(1.0f + P::exp(P::divc(vs, FC(-12.7), 1.0f / (FC(-12.7))))));
         }
         o.g_Kur = FC(0.005) + P::div(FC(0.05), 1.0f + P::exp(P::div(V - 15.0f, -13.0f)));         // :415
-        o.f_NaK = P::rcp((1.0f + FC(0.1245) * P::exp(P::div(FC(-0.1 * Fd) * V, RT))) +
-                         FC(0.0365 * sigma) * P::exp(P::div(FC(-Fd) * V, RT)));                    // :417
+        o.f_NaK = P::rcp((1.0f + FC(0.1245) * P::exp(P::divc(FC(-0.1 * Fd) * V, RT, 1.0f / (RT)))) +
+                         FC(0.0365 * sigma) * P::exp(P::divc(FC(-Fd) * V, RT, 1.0f / (RT))));                    // :417
         const float i_NaCad = FC((K_mNa * K_mNa * K_mNa + Na_o * Na_o * Na_o) * (K_mCa + Ca_o)) *
-                              (1.0f + FC(K_sat) * P::exp(P::div((FC(gamma_ - 1.0) * V) * FC(Fd), RT)));  // :419
+                              (1.0f + FC(K_sat) * P::exp(P::divc((FC(gamma_ - 1.0) * V) * FC(Fd), RT, 1.0f / (RT))));  // :419
         o.i_NaCaa = P::div(FC(Cm * I_NaCa_max) * (P::exp(P::div(FC(gamma_ * Fd) * V, RT)) * FC(Ca_o)), i_NaCad);  // :421
         o.i_NaCab = P::div(FC(Cm * I_NaCa_max) *
                                (P::exp(P::div(FC((gamma_ - 1.0) * Fd) * V, RT)) * FC(Na_o * Na_o * Na_o)),
@@ -396,7 +411,7 @@ struct Courtemanche {
         o[i_ui] = rush_larsen<P>(s[i_ui], q.ui_inf, q.tau_ui, mdt_s);
         o[i_xr] = rush_larsen<P>(s[i_xr], q.xr_inf, q.tau_xr, mdt_s);
         o[i_xs] = rush_larsen<P>(s[i_xs], q.xs_inf, q.tau_xs, mdt_s);
-        const float f_Ca_inf = P::rcp(1.0f + P::div(s[iCa_i], FC(0.00035)));
+        const float f_Ca_inf = P::rcp(1.0f + P::divc(s[iCa_i], FC(0.00035), 1.0f / (FC(0.00035))));
         o[i_f_Ca] = rush_larsen_c(s[i_f_Ca], f_Ca_inf, k.em1_fCa);
         // potassium, court.py:191-204
         const float E_K = RTF * P::log(P::div(FC(K_o), s[iK_i]));
@@ -410,13 +425,13 @@ struct Courtemanche {
         const float i_NaK = P::div(FC(Cm * i_NaK_max) * q.f_NaK, 1.0f + P::sqrt(pow3(nr))) * FC(K_o / (K_o + Km_K_o));
         const float i_B_K = FC(Cm * g_B_K) * vEK;
         o[iK_i] = s[iK_i] +
-                  P::div(2.0f * i_NaK - (((((i_K1 + i_to) + i_Kur) + i_Kr) + i_Ks) + i_B_K), ViF) * dts;
+                  P::divc(2.0f * i_NaK - (((((i_K1 + i_to) + i_Kur) + i_Kr) + i_Ks) + i_B_K), ViF, 1.0f / (ViF)) * dts;
         // sodium, court.py:206-215
         const float E_Na = RTF * P::log(P::div(FC(Na_o), s[iNa_i]));
         const float i_Na = (((FC(Cm * g_Na) * pow3(s[i_m])) * s[i_h]) * s[i_j]) * (V - E_Na);
         const float i_NaCa = q.i_NaCaa * pow3(s[iNa_i]) - q.i_NaCab * s[iCa_i];
         const float i_B_Na = FC(Cm * g_B_Na) * (V - E_Na);
-        o[iNa_i] = s[iNa_i] + P::div(-3.0f * i_NaK - ((3.0f * i_NaCa + i_B_Na) + i_Na), ViF) * k.dtf;
+        o[iNa_i] = s[iNa_i] + P::divc(-3.0f * i_NaK - ((3.0f * i_NaCa + i_B_Na) + i_Na), ViF, 1.0f / (ViF)) * k.dtf;
         // calcium currents + potential, court.py:217-229
         const float i_st = 0.0f;
         const float i_Ca_L = (((k.c_CaL * s[i_d]) * s[i_f]) * s[i_f_Ca]) * (V - 65.0f);
@@ -425,29 +440,29 @@ struct Courtemanche {
         const float i_B_Ca = FC(Cm * g_B_Ca) * (V - E_Ca);
         const float isum = (((((((((((i_Na + i_K1) + i_to) + i_Kur) + i_Kr) + i_Ks) + i_B_Na) + i_B_Ca) + i_NaK) +
                               i_CaP) + i_NaCa) + i_Ca_L) + i_st;
-        const float DV = V + P::div(-isum, FC(Cm)) * k.dtf;
+        const float DV = V + P::divc(-isum, FC(Cm), 1.0f / (FC(Cm))) * k.dtf;
         o[iV] = DV + k.ddt * lap;
         // SR release / uptake, court.py:232-256
         const float i_rel = (((FC(K_rel) * (s[i_u] * s[i_u])) * s[i_v]) * s[i_w]) * (s[iCa_rel] - s[iCa_i]);
-        const float i_tr = P::div(s[iCa_up] - s[iCa_rel], FC(tau_tr));
+        const float i_tr = P::divc(s[iCa_up] - s[iCa_rel], FC(tau_tr), 1.0f / (FC(tau_tr)));
         {
             const float t = s[iCa_rel] + FC(Km_CSQN);
             o[iCa_rel] = s[iCa_rel] + ((i_tr - i_rel) * P::rcp(1.0f + P::div(FC(CSQN_max * Km_CSQN), t * t))) * dts;
         }
         const float Fn = 1000.0f * (FC(1.0e-15 * V_rel) * i_rel -
                                     FC(1.0e-15 / (2.0 * Fd)) * (0.5f * i_Ca_L - FC(0.2) * i_NaCa));
-        const float u_inf = P::rcp(1.0f + P::exp(P::div(-(Fn - FC(3.4175e-13)), FC(1.367e-15))));
+        const float u_inf = P::rcp(1.0f + P::exp(P::divc(-(Fn - FC(3.4175e-13)), FC(1.367e-15), 1.0f / (FC(1.367e-15)))));
         // MODE_ALL (court_ultra) integrates u with dt: expm1(float(-dt/tau_u)) is k.em1_u there too
         o[i_u] = rush_larsen_c(s[i_u], u_inf, k.em1_u);
         const float tau_v = FC(1.91) + FC(2.09) * u_inf;
-        const float v_inf = 1.0f - P::rcp(1.0f + P::exp(P::div(-(Fn - FC(6.835e-14)), FC(1.367e-15))));
+        const float v_inf = 1.0f - P::rcp(1.0f + P::exp(P::divc(-(Fn - FC(6.835e-14)), FC(1.367e-15), 1.0f / (FC(1.367e-15)))));
         o[i_v] = rush_larsen<P>(s[i_v], v_inf, tau_v, mdt_s);
         const float i_up = P::div(FC(I_up_max), 1.0f + P::div(FC(K_up), s[iCa_i]));
-        const float i_up_leak = P::div(FC(I_up_max) * s[iCa_up], FC(Ca_up_max));
-        o[iCa_up] = s[iCa_up] + (i_up - (i_up_leak + P::div(i_tr * FC(V_rel), FC(V_up)))) * dts;
+        const float i_up_leak = P::divc(FC(I_up_max) * s[iCa_up], FC(Ca_up_max), 1.0f / (FC(Ca_up_max)));
+        o[iCa_up] = s[iCa_up] + (i_up - (i_up_leak + P::divc(i_tr * FC(V_rel), FC(V_up), 1.0f / (FC(V_up))))) * dts;
         // intracellular calcium, court.py:258-265
-        const float B1 = P::div(2.0f * i_NaCa - ((i_CaP + i_Ca_L) + i_B_Ca), FC(2.0 * V_i * Fd)) +
-                         P::div(FC(V_up) * (i_up_leak - i_up) + i_rel * FC(V_rel), FC(V_i));
+        const float B1 = P::divc(2.0f * i_NaCa - ((i_CaP + i_Ca_L) + i_B_Ca), FC(2.0 * V_i * Fd), 1.0f / (FC(2.0 * V_i * Fd))) +
+                         P::divc(FC(V_up) * (i_up_leak - i_up) + i_rel * FC(V_rel), FC(V_i), 1.0f / (FC(V_i)));
         const float t1 = s[iCa_i] + FC(Km_TRPN), t2 = s[iCa_i] + FC(Km_CMDN);
         const float B2 = (1.0f + P::div(FC(TRPN_max * Km_TRPN), t1 * t1)) + P::div(FC(CMDN_max * Km_CMDN), t2 * t2);
         o[iCa_i] = s[iCa_i] + P::div(B1, B2) * dts;

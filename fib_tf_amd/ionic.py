@@ -55,9 +55,12 @@ class IonicModel:
         self.dt_per_step = 1
         self.cl_observer = None
         self._stepper = None
-        self._sess_open = False
+        # config['fast_math'] (default True): hardware exp/log/rcp/sqrt and reciprocal-multiply for the
+        # model constants; False selects the rounding-faithful policy (IEEE-equivalent division, ocml
+        # expf/tanhf/expm1f/logf): one float32 rounding per reference op.  Both are parity-tested; the
+        # stencil and the phase-field term are bit-identical to the reference under either.
         for key, default in (('timeline', False), ('timeline_name', 'timeline.json'), ('save_graph', False),
-                             ('device', int(os.environ.get('LOCAL_RANK', '0'))), ('fast_math', False)):
+                             ('device', int(os.environ.get('LOCAL_RANK', '0'))), ('fast_math', True)):
             if not hasattr(self, key):
                 setattr(self, key, default)
 

@@ -10,9 +10,10 @@ import argparse
 import bench
 
 VARIANTS = {
-    'fenton': ['10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512', '5,32,16,256',
+    'fenton': ['10,44,25,-4', '10,44,25,-3', '10,44,25,-5', '10,44,25,-6', '10,44,32,-4', '5,54,21,-4', '5,54,21,-3',
+               '5,54,32,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512', '5,32,16,256',
                '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256'],
-    'br': ['5,32,32,256', '5,32,32,512', '1,64,16,256', '1,64,4,256'],
+    'br': ['3,58,19,-2', '5,54,21,-3', '5,54,21,-2', '5,32,32,256', '5,32,32,512', '1,64,16,256', '1,64,4,256'],
     'court': ['1,64,4,256', '1,64,8,256'],
 }
 
@@ -21,7 +22,7 @@ def main():
     model = sys.argv[1] if len(sys.argv) > 1 else 'fenton'
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     fast = len(sys.argv) > 3 and sys.argv[3] == 'fast'
-    args = argparse.Namespace(model=model, size=size, fast=fast, no_cheby=False, skip=False)
+    args = argparse.Namespace(model=model, size=size, exact=not fast, no_cheby=False, skip=False)
     for v in VARIANTS[model] + sys.argv[4:]:
         os.environ['FIBHIP_VARIANT'] = v
         m, _ = bench.make_model(args)
