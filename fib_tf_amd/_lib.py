@@ -72,7 +72,7 @@ _lib = None
 
 def build(force=False, verbose=False):
     """compile csrc/fibhip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
-    deps = [SRC, HDR, os.path.join(HERE, 'csrc', 'kernels.hpp'), os.path.join(HERE, 'csrc', 'models.hpp')]
+    deps = [SRC, HDR] + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "models.hpp", "fenton_step.inc", "br_step.inc", "court_step.inc", "court_inter.inc")]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
