@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'traffic_r01.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 # algorithmic bytes per cell per sub-step: every state array read once + every updated
 # array written once, float32, + 4 B for the phase field
@@ -70,7 +71,7 @@ def cpu_baseline(args, seconds=12.0):
     t0 = time.perf_counter()
     run(slab, 40)
     per = (time.perf_counter() - t0) / 40
-    n = int(max(40, min(seconds / per, 4000)))
+    n = int(max(40, min(seconds / per, 200000)))
     t0 = time.perf_counter()
     run(slab, n)
     dt = time.perf_counter() - t0
@@ -151,6 +152,12 @@ def bench_single(args):
     us_per_launch = ms * 1000.0 / launches
     abytes = ALGO_BYTES[args.model] + (4 if m.phase is not None else 0)
     achieved = abytes * cells * fused / (us_per_launch * 1e-6) / 1e9
+    traffic = None
+    try:                                              # measured offline (PMC cannot run inside the bench)
+        key = '%s/%s/%dx%d/K%d' % (args.model, 'exact' if args.exact else 'fast', m.height, m.width, fused)
+        traffic = json.load(open(TRAFFIC_JSON)).get(key, {}).get('hbm_bytes_per_launch_corrected')
+    except (OSError, ValueError):
+        pass
     out = {
         'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d' % (
             {'fenton': '4v', 'br': 'BR', 'court': 'Courtemanche'}[args.model], m.height, m.width),
@@ -164,8 +171,8 @@ def bench_single(args):
                    'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
                    'parallelism': 'single device'},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                     'kernel': 'tick_kernel<%s, K=%d>' % (args.model, fused), 'us_per_launch': round(us_per_launch, 3),
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'kernel': '%s<%s, K=%d>' % ('strip_kernel' if fused > 1 and args.model == 'fenton' else 'tick_kernel', args.model, fused), 'us_per_launch': round(us_per_launch, 3),
                      'algorithmic_bytes_per_launch': int(abytes * cells * fused),
                      'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
                              'one-step-per-pass implementation must move, K fused sub-steps move them once'},

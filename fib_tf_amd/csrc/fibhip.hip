@@ -61,7 +61,8 @@ static hipError_t launch_tick(hipStream_t st, const LaunchCtx &c)
 {
     Geo g = c.g;
     g.tiles_x = (g.W + TX - 1) / TX;
-    const int tiles_y = (g.r1 - g.r0 + TY - 1) / TY;
+    g.ty_a = (g.r1 > g.r0) ? (g.r1 - g.r0 + TY - 1) / TY : 0;
+    const int tiles_y = g.ty_a + ((g.rb1 > g.rb0) ? (g.rb1 - g.rb0 + TY - 1) / TY : 0);
     g.ntiles = g.tiles_x * tiles_y;
     if (g.ntiles <= 0) return hipSuccess;
     PtrTab<M::NVAR> pt;
@@ -80,7 +81,8 @@ static hipError_t launch_strip(hipStream_t st, const LaunchCtx &c)
 {
     Geo g = c.g;
     g.tiles_x = (g.W + TX - 1) / TX;
-    const int tiles_y = (g.r1 - g.r0 + TY - 1) / TY;
+    g.ty_a = (g.r1 > g.r0) ? (g.r1 - g.r0 + TY - 1) / TY : 0;
+    const int tiles_y = g.ty_a + ((g.rb1 > g.rb0) ? (g.rb1 - g.rb0 + TY - 1) / TY : 0);
     g.ntiles = g.tiles_x * tiles_y;
     if (g.ntiles <= 0) return hipSuccess;
     PtrTab<M::NVAR> pt;
@@ -152,8 +154,8 @@ static const Variant g_variants[] = {
     V4(Fenton, FIBHIP_FENTON4V, 0, 5, 32, 16, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 2, 64, 16, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 2, 32, 32, 256),
-    V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 4, 256),
+    V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
@@ -161,16 +163,16 @@ static const Variant g_variants[] = {
     S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 18, 2),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
-    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
+    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
     S4(BeelerReuter, FIBHIP_BR, 1, 3, 58, 19, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 18, 2),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 512),
-    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 16, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
+    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 16, 256),
     // ---- Courtemanche (mode 0 fast set, 2 all variables) ----
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 4, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
@@ -454,6 +456,8 @@ static Geo base_geo(const fibhip_ctx *h)
     g.row_off = h->d.row_offset;
     g.r0 = 0;
     g.r1 = h->d.height;
+    g.rb0 = g.rb1 = 0;
+    g.ty_a = 0;
     g.tiles_x = g.ntiles = 0;
     return g;
 }
@@ -545,12 +549,16 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     c.consts = consts_of(h);
 }
 
-static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, LaunchCtx &c, int r0, int r1)
+// one launch over the rows [r0, r1) and, optionally, a second band [rb0, rb1)
+static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, LaunchCtx &c, int r0, int r1, int rb0 = 0,
+                        int rb1 = 0)
 {
-    if (r1 <= r0) return 0;
+    if (r1 <= r0 && rb1 <= rb0) return 0;
     c.g = base_geo(h);
     c.g.r0 = r0;
-    c.g.r1 = r1;
+    c.g.r1 = r1 > r0 ? r1 : r0;
+    c.g.rb0 = rb0;
+    c.g.rb1 = rb1 > rb0 ? rb1 : rb0;
     HIPCHK(it.fn(st, c));
     h->launches++;
     return 0;
@@ -602,8 +610,7 @@ extern "C" int fibhip_step_edges(fibhip_t h)
         const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
         int t1 = h->d.ghost_top ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
         int b0 = h->d.ghost_bottom ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
-        if (int rc = launch_range(h, h->s0, it, c, r0, t1)) return rc;
-        if (int rc = launch_range(h, h->s0, it, c, b0, r1)) return rc;
+        if (int rc = launch_range(h, h->s0, it, c, r0, t1, b0, r1)) return rc;   // both strips, one launch
         memcpy(h->nxt, nxt, sizeof nxt);
     }
     h->phase_of_tick = 1;
@@ -768,7 +775,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
         if (phi) {
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
-            g.H = g.Hg = H; g.W = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.tiles_x = g.ntiles = 0;
+            g.H = g.Hg = H; g.W = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
             hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
         }
         const float mdt = (float)(-dt);

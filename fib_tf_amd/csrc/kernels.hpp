@@ -29,9 +29,23 @@ struct Geo {
     int H, W;        // rows / cols of this slab (pitch == W)
     int Hg;          // rows of the whole grid
     int row_off;     // global row of local row 0
-    int r0, r1;      // local rows [r0, r1) this launch computes and stores
+    int r0, r1;      // local rows [r0, r1) this launch computes and stores ...
+    int rb0, rb1;    // ... and, when ty_a < tile rows, a second band [rb0, rb1) served by the same launch
+    int ty_a;        //     (the two edge strips of a row block); tile rows >= ty_a belong to the second band
     int tiles_x, ntiles;
 };
+
+// tile row `by` -> first local row of the tile and the end of the band it belongs to
+static FIB_DEV void tile_rows(const Geo &g, int by, int TY, int &y0, int &rend)
+{
+    if (by < g.ty_a) {
+        y0 = g.r0 + by * TY;
+        rend = g.r1;
+    } else {
+        y0 = g.rb0 + (by - g.ty_a) * TY;
+        rend = g.rb1;
+    }
+}
 
 template <int NVAR>
 struct PtrTab {
@@ -93,7 +107,9 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
     if (tile >= g.ntiles) return;                                  // whole workgroup, before any barrier
     const int tid = threadIdx.x;
     const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
-    const int x0 = bx * TX, y0 = g.r0 + by * TY;                   // tile origin (local rows)
+    int y0, rend;
+    tile_rows(g, by, TY, y0, rend);
+    const int x0 = bx * TX;                                        // tile origin (local rows: y0)
     const int cx0 = x0 - (K - 1), cy0 = y0 - (K - 1);              // compute-box origin
 
     // ---- potential tile, through the boundary clamp -------------------------------------------
@@ -142,7 +158,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 if (gx == 1) f |= F_LEFT | (cxx >= 1 ? F_LEFT2 : 0u);
                 if (gx == g.W - 2) f |= F_RIGHT | (cxx <= CX - 2 ? F_RIGHT2 : 0u);
             }
-            if (gy >= y0 && gy < min(y0 + TY, g.r1) && gx >= x0 && gx < x0 + TX) f |= F_STORE;
+            if (gy >= y0 && gy < min(y0 + TY, rend) && gx >= x0 && gx < x0 + TX) f |= F_STORE;
         }
         fl[j] = f;
     }
@@ -251,7 +267,9 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
-    const int x0 = bx * TX, y0 = g.r0 + by * TY;
+    int y0, rend;
+    tile_rows(g, by, TY, y0, rend);
+    const int x0 = bx * TX;
     const int cx0 = x0 - (K - 1), cy0 = y0 - (K - 1);
     const int gx = cx0 - 1 + lane;                                  // this lane's global column
     const int xx = clampi(gx, 1, g.W - 2);
@@ -394,7 +412,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = cy0 + wave * R + r;
-        if (store_col && gy >= y0 && gy < min(y0 + TY, g.r1) && gy < g.H) {
+        if (store_col && gy >= y0 && gy < min(y0 + TY, rend) && gy < g.H) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if ((WMASK >> v) & 1u) pt.out[v][off[r]] = s[r][v];

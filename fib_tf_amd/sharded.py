@@ -128,9 +128,8 @@ class ShardedStepper:
         # rehearse this driver with several ranks on ONE GPU, and by the CPU tests) gets host staging.
         self.staged = dist.get_backend(group) != 'nccl'
         shape = (self.halo_n, self.g, width)
-        mk = (lambda: torch.empty(shape, dtype=torch.float32)) if self.staged else (lambda: self.eng.empty(shape))
-        self.recv_up = mk() if self.up is not None else None
-        self.recv_down = mk() if self.down is not None else None
+        self.recv_up = torch.empty(shape, dtype=torch.float32) if self.staged and self.up is not None else None
+        self.recv_down = torch.empty(shape, dtype=torch.float32) if self.staged and self.down is not None else None
         self.comm_s = 0.0
 
     # ---- data movement between the global arrays and this block ---------------------------------
@@ -176,28 +175,44 @@ class ShardedStepper:
         torch, dist, e, g = self.torch, self.dist, self.eng, self.g
         e.step_edges()
         t0 = time.perf_counter()
-        ops, keep = [], []
-        if self.up is not None:
-            s = torch.stack([self._slab_view(v, True)[self.gt:self.gt + g] for v in range(self.halo_n)])
-            s = s.cpu() if self.staged else s
-            keep.append(s)
-            ops += [dist.P2POp(dist.isend, s, self.up, self.group), dist.P2POp(dist.irecv, self.recv_up, self.up, self.group)]
-        if self.down is not None:
-            b = self.gt + self.rows
-            s = torch.stack([self._slab_view(v, True)[b - g:b] for v in range(self.halo_n)])
-            s = s.cpu() if self.staged else s
-            keep.append(s)
-            ops += [dist.P2POp(dist.isend, s, self.down, self.group),
-                    dist.P2POp(dist.irecv, self.recv_down, self.down, self.group)]
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        e.step_interior()                                   # overlaps with the messages
-        for r in reqs:
-            r.wait()
-        for v in range(self.halo_n):
+        b = self.gt + self.rows
+        if not self.staged:
+            # RCCL: every message is a contiguous g x W block of a slab — send straight out of the owned
+            # rows, receive straight into the ghost rows; all messages of the tick form one group.
+            ops = []
+            for v in range(self.halo_n):
+                a = self._slab_view(v, True)
+                if self.up is not None:
+                    ops += [dist.P2POp(dist.isend, a[self.gt:self.gt + g], self.up, self.group),
+                            dist.P2POp(dist.irecv, a[:g], self.up, self.group)]
+                if self.down is not None:
+                    ops += [dist.P2POp(dist.isend, a[b - g:b], self.down, self.group),
+                            dist.P2POp(dist.irecv, a[b:], self.down, self.group)]
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            e.step_interior()                               # overlaps with the messages
+            for r in reqs:
+                r.wait()
+        else:
+            ops, keep = [], []
             if self.up is not None:
-                self._slab_view(v, True)[:g].copy_(self.recv_up[v])
+                s = torch.stack([self._slab_view(v, True)[self.gt:self.gt + g] for v in range(self.halo_n)]).cpu()
+                keep.append(s)
+                ops += [dist.P2POp(dist.isend, s, self.up, self.group),
+                        dist.P2POp(dist.irecv, self.recv_up, self.up, self.group)]
             if self.down is not None:
-                self._slab_view(v, True)[self.gt + self.rows:].copy_(self.recv_down[v])
+                s = torch.stack([self._slab_view(v, True)[b - g:b] for v in range(self.halo_n)]).cpu()
+                keep.append(s)
+                ops += [dist.P2POp(dist.isend, s, self.down, self.group),
+                        dist.P2POp(dist.irecv, self.recv_down, self.down, self.group)]
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            e.step_interior()
+            for r in reqs:
+                r.wait()
+            for v in range(self.halo_n):
+                if self.up is not None:
+                    self._slab_view(v, True)[:g].copy_(self.recv_up[v])
+                if self.down is not None:
+                    self._slab_view(v, True)[b:].copy_(self.recv_down[v])
         self.comm_s += time.perf_counter() - t0
         e.step_commit()
 
