@@ -105,6 +105,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;                                  // whole workgroup, before any barrier
+    auto &&kk = M::pinned(k);
     const int tid = threadIdx.x;
     const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
     int y0, rend;
@@ -178,7 +179,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float C = A[i];
                 float l = stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
                 if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
-                M::template step<P, MODE>(s[j], C, l, k, sub0 + st);
+                M::template step<P, MODE>(s[j], C, l, kk, sub0 + st);
             }
         }
         if (K > 1 && st + 1 < K) {
@@ -264,6 +265,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;
     FIB_STAMP(0);
+    auto &&kk = M::pinned(k);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
@@ -348,6 +350,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
                 win[q][1] = A[i];
                 win[q][2] = A[i + 1];
             }
+            float lp[R], cc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float l = stencil9(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
@@ -355,7 +358,14 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
                 if (PHASE)
                     l = l + phase_term<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r], pq4[r],
                                           pr4[r]);
-                M::template step<P, MODE>(s[r], win[r + 1][1], l, k, sub0 + st);
+                lp[r] = l;
+                cc[r] = win[r + 1][1];
+            }
+            if constexpr (M::HAS_VEC) {
+                M::template stepN<P, MODE, R>(s, cc, lp, kk, sub0 + st);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) M::template step<P, MODE>(s[r], cc[r], lp[r], kk, sub0 + st);
             }
         } else {
 #pragma unroll
@@ -367,7 +377,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
                     const float SW = A[i + LP - 1], S = A[i + LP], SE = A[i + LP + 1];
                     float l = stencil9(N, S, Wv, E, NW_, SW, NE, SE, C);
                     if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[r], pdx[r], pq4[r], pr4[r]);
-                    M::template step<P, MODE>(s[r], C, l, k, sub0 + st);
+                    M::template step<P, MODE>(s[r], C, l, kk, sub0 + st);
                 }
             }
         }
@@ -404,7 +414,9 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
                 }
             }
         }
+#if !(defined(FIB_STAMPS) && defined(FIB_DIAG_NO_BARRIER))
         if (st + 1 < K) __syncthreads();
+#endif
         FIB_STAMP(3 + st);
     }
 

@@ -24,6 +24,56 @@ namespace fib {
 
 #define FIB_DEV __device__ __forceinline__
 
+// ---- R-wide value type --------------------------------------------------------------------------
+// The SIMD issues a wave's next VALU instruction at full rate only if it does not depend on the one
+// just issued (measured, tools/ubench/valu.hip: one dependent chain 2.1 ns per instruction per SIMD,
+// two or more independent chains 1.2 ns, at 4 waves per SIMD).  A lane of the strip kernel owns R
+// independent cells, so the kinetics are written once over `vf<R>`: every source line expands to R
+// adjacent independent instructions (operation-major order) instead of R long dependent chains.
+template <int R>
+struct vf {
+    float v[R];
+};
+template <int R>
+struct vm {
+    bool v[R];
+};
+#define FIB_VEC_BINOP(OP)                                                                    \
+    template <int R> FIB_DEV vf<R> operator OP(const vf<R> &a, const vf<R> &b)               \
+    { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] OP b.v[r]; return o; }   \
+    template <int R> FIB_DEV vf<R> operator OP(const vf<R> &a, float b)                       \
+    { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] OP b; return o; }        \
+    template <int R> FIB_DEV vf<R> operator OP(float a, const vf<R> &b)                       \
+    { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a OP b.v[r]; return o; }
+FIB_VEC_BINOP(+)
+FIB_VEC_BINOP(-)
+FIB_VEC_BINOP(*)
+template <int R> FIB_DEV vf<R> operator-(const vf<R> &a)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = -a.v[r]; return o; }
+template <int R> FIB_DEV vm<R> vgt(const vf<R> &a, float b)
+{ vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] > b; return o; }
+template <int R> FIB_DEV vf<R> vsel(const vm<R> &m, const vf<R> &a, const vf<R> &b)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = m.v[r] ? a.v[r] : b.v[r]; return o; }
+template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, float b, const vf<R> &c)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b, c.v[r]); return o; }
+template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, float b, float c)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b, c); return o; }
+template <int R, class F> FIB_DEV vf<R> vmap(const vf<R> &a, F f)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r]); return o; }
+template <class T> struct bcast;
+template <> struct bcast<float> { static FIB_DEV float of(float x) { return x; } };
+template <int R> struct bcast<vf<R>> { static FIB_DEV vf<R> of(float x) { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = x; return o; } };
+template <class T> FIB_DEV T T_of(float x) { return bcast<T>::of(x); }
+// clamp(a*b + c, 0, 1) in one instruction (v_fma_f32 ... clamp)
+template <int R> FIB_DEV vf<R> vfma_sat(const vf<R> &a, float b, float c)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_amdgcn_fmed3f(__builtin_fmaf(a.v[r], b, c), 0.0f, 1.0f); return o; }
+FIB_DEV float vfma_sat(float a, float b, float c) { return __builtin_amdgcn_fmed3f(__builtin_fmaf(a, b, c), 0.0f, 1.0f); }
+// scalar spellings of the same helpers, so one body serves float and vf<R>
+FIB_DEV bool vgt(float a, float b) { return a > b; }
+FIB_DEV float vsel(bool m, float a, float b) { return m ? a : b; }
+FIB_DEV float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <class F> FIB_DEV float vmap(float a, F f) { return f(a); }
+
 // Division by a value whose correctly rounded reciprocal rc = RN(1/c) is known (a compile-time
 // constant, or the per-cell 1/(4ϕ) prepared once): q = RN(a*rc); r = a - q*c (exact, one FMA);
 // RN(q + r*rc) is the correctly rounded quotient RN(a/c) (Markstein's theorem) — bit-identical to
@@ -31,26 +81,43 @@ namespace fib {
 // over all 2^23 significands for every constant of the three models (tools/ubench/divtest.c);
 // it can differ only when a/c is subnormal (by at most one subnormal ulp).
 struct Exact {
-    static constexpr bool CONTRACT = false;   // never fuse a*b+c: the reference rounds every op
-    static FIB_DEV float divc(float a, float c, float rc)
+    // a*b + c: the reference rounds the product and the sum separately
+    template <class T, class B, class C>
+    static FIB_DEV auto mad(const T &a, const B &b, const C &c) { return a * b + c; }
+    template <class T>
+    static FIB_DEV T divc(const T &a, float c, float rc)
     {
-        const float q = a * rc;
-        const float r = __builtin_fmaf(-q, c, a);
-        return __builtin_fmaf(r, rc, q);
+        const T q = a * rc;
+        const T r = vfma(-q, c, a);
+        return vfma(r, rc, q);
     }
+    template <class T>
+    static FIB_DEV T tanhv(const T &a) { return vmap(a, [](float x) { return tanhf(x); }); }
     static FIB_DEV float div(float a, float b) { return a / b; }
     static FIB_DEV float rcp(float a) { return 1.0f / a; }
     static FIB_DEV float exp(float a) { return expf(a); }
     static FIB_DEV float expm1(float a) { return expm1f(a); }
     static FIB_DEV float log(float a) { return logf(a); }
-    static FIB_DEV float tanh(float a) { return tanhf(a); }
+    static FIB_DEV float tanh(float a) { return tanhf(a); }   // == tanhv<float>
     static FIB_DEV float sqrt(float a) { return sqrtf(a); }
 };
 
 struct Fast {
-    static constexpr bool CONTRACT = true;    // the kinetics may use FMA (fewer roundings, ~25 % fewer
-                                              // instructions); stencil + phase term never do
-    static FIB_DEV float divc(float a, float, float rc) { return a * rc; }
+    // a*b + c as ONE fused multiply-add, written explicitly (never left to -ffp-contract): every kernel
+    // variant then rounds identically, so fusion depth / tile shape never change a bit of the result
+    template <class T, class C>
+    static FIB_DEV T mad(const T &a, float b, const C &c) { return vfma(a, b, c); }
+    template <class T>
+    static FIB_DEV T divc(const T &a, float, float rc) { return a * rc; }
+    template <class T>
+    static FIB_DEV T tanhv(const T &a)
+    {   // 1 - 2/(exp(2a)+1), operation-major over the R cells
+        const T t = a * (2.0f * 1.44269504088896340736f);
+        const T e = vmap(t, [](float x) { return __builtin_amdgcn_exp2f(x); });
+        const T d = e + 1.0f;
+        const T q = vmap(d, [](float x) { return __builtin_amdgcn_rcpf(x); });
+        return 1.0f - 2.0f * q;
+    }
     static FIB_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
     static FIB_DEV float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
     static FIB_DEV float exp(float a) { return __expf(a); }
@@ -58,19 +125,20 @@ struct Fast {
     // ~1 ulp(1) = 6e-8, which is below the float32 resolution of the gate value it multiplies into.
     static FIB_DEV float expm1(float a) { return __expf(a) - 1.0f; }
     static FIB_DEV float log(float a) { return __logf(a); }
-    static FIB_DEV float tanh(float a)
-    {   // 1 - 2/(exp(2a)+1); saturates correctly for |a| large (exp -> inf or 0)
-        return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * a) + 1.0f);
-    }
+    static FIB_DEV float tanh(float a) { return tanhv<float>(a); }
     static FIB_DEV float sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 };
 
 static FIB_DEV float sgnf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
-// (1 + sign(x)) * 0.5 and (1 - sign(x)) * 0.5 (fenton.py:73-79) as selects: the same three values
-// {0, 0.5, 1} bit for bit, 4 instructions instead of 7
-static FIB_DEV float heav(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? 0.0f : 0.5f); }
-static FIB_DEV float heav_not(float x) { return x > 0.0f ? 0.0f : (x < 0.0f ? 1.0f : 0.5f); }
 static FIB_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// (1 + sign(x)) * 0.5 and (1 - sign(x)) * 0.5 (fenton.py:73-79): the three values {0, 0.5, 1}, produced as
+// clamp(0.5 +- x * 2^27, 0, 1) — one instruction, no compare (compares write SGPRs and issue at ~60 %
+// of the plain-VALU rate, tools/ubench/valu2.hip).  Exact for every argument this model forms: x is
+// U - 0.23 or U - 0.3, an exact float difference whose nonzero magnitude is at least one ulp of the
+// threshold (2^-26), so |x| * 2^27 >= 2 whenever x != 0.
+template <class T> static FIB_DEV T heav(const T &x) { return vfma_sat(x, 134217728.0f, 0.5f); }
+template <class T> static FIB_DEV T heav_not(const T &x) { return vfma_sat(x, -134217728.0f, 0.5f); }
 
 // rush_larsen, ionic.py:115-123.  mdt = float(-dt)
 template <class P>
@@ -104,17 +172,38 @@ struct Fenton {
     template <class P, int MODE>
     static FIB_DEV void step(float (&s)[NVAR], float U0, float lap, const Consts &k, int)
     {
-        if constexpr (P::CONTRACT) step_fused<P>(s, U0, lap, k); else step_plain<P>(s, U0, lap, k);
+        body<P, float>(s, U0, lap, k);
     }
-    template <class P>
-    static FIB_DEV void step_plain(float (&s)[NVAR], float U0, float lap, const Consts &k)
+    // the R cells of a lane at once (strip kernel): same arithmetic per cell, operation-major order
+    static constexpr bool HAS_VEC = true;
+    template <class P, int MODE, int R>
+    static FIB_DEV void stepN(float (&s)[R][NVAR], const float (&U0)[R], const float (&lap)[R], const Consts &k, int)
     {
-#include "fenton_step.inc"
+        vf<R> t[NVAR], u0, l;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int v = 0; v < NVAR; ++v) t[v].v[r] = s[r][v];
+            u0.v[r] = U0[r];
+            l.v[r] = lap[r];
+        }
+        body<P, vf<R>>(t, u0, l, k);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < NVAR; ++v) s[r][v] = t[v].v[r];
     }
-    template <class P>
-    static FIB_DEV void step_fused(float (&s)[NVAR], float U0, float lap, const Consts &k)
+    // keep the per-step scalars in VGPRs: a VALU op with an SGPR source issues at ~60 % of the rate
+    // of an all-VGPR one (tools/ubench/valu2.hip)
+    static FIB_DEV Consts pinned(const Consts &k)
     {
-#pragma clang fp contract(fast)
+        Consts c = k;
+        asm volatile("" : "+v"(c.dt), "+v"(c.ddt));
+        return c;
+    }
+    template <class P, class T>
+    static FIB_DEV void body(T (&s)[NVAR], const T &U0, const T &lap, const Consts &k)
+    {
 #include "fenton_step.inc"
     }
 };
@@ -125,6 +214,8 @@ struct Fenton {
 struct BeelerReuter {
     static constexpr int NVAR = 8;                // V C M H J D F XI, br.py:87-94
     static constexpr int DEFAULT_STEPS = 5;       // br.py:98-107
+    static constexpr bool HAS_VEC = false;
+    template <class C> static FIB_DEV const C &pinned(const C &k) { return k; }
     enum { MODE_DIRECT = 0, MODE_CHEBY = 1 };
     struct Consts {
         float dt, ddt;
@@ -152,39 +243,20 @@ struct BeelerReuter {
         tau = P::div(1.0f, a + b);
     }
     // expand_chebyshev device part, br.py:329-331:  r = d0; r += d_i * S_i  (i ascending)
+    // (P unused: the degree-8 sums keep the reference's rounding points under both policies — they
+    // amplify an ulp by ~1e2, and Beeler-Reuter is not instruction-bound at one sub-step per launch)
     template <class P>
     static FIB_DEV float cheb(const float *d, const float (&S)[9])
     {
-        if constexpr (false && P::CONTRACT) {
-#pragma clang fp contract(fast)
-            float r = d[0];
+        float r = d[0];
 #pragma unroll
-            for (int i = 1; i <= 8; ++i) r = r + d[i] * S[i];   // 8 FMAs: same order, fewer roundings
-            return r;
-        } else {
-            float r = d[0];
-#pragma unroll
-            for (int i = 1; i <= 8; ++i) r = r + d[i] * S[i];
-            return r;
-        }
+        for (int i = 1; i <= 8; ++i) r = r + d[i] * S[i];
+        return r;
     }
 
     template <class P, int MODE>
     static FIB_DEV void step(float (&s)[NVAR], float V0, float lap, const Consts &k, int sub)
     {
-        // measured: Beeler-Reuter at one sub-step per launch is launch/latency-bound, FMA contraction buys
-        // nothing there, so both policies keep the reference's rounding points
-        step_plain<P, MODE>(s, V0, lap, k, sub);
-    }
-    template <class P, int MODE>
-    static FIB_DEV void step_plain(float (&s)[NVAR], float V0, float lap, const Consts &k, int sub)
-    {
-#include "br_step.inc"
-    }
-    template <class P, int MODE>
-    static FIB_DEV void step_fused(float (&s)[NVAR], float V0, float lap, const Consts &k, int sub)
-    {
-#pragma clang fp contract(fast)
 #include "br_step.inc"
     }
 };
@@ -195,6 +267,8 @@ struct BeelerReuter {
 struct Courtemanche {
     static constexpr int NVAR = 21;
     static constexpr int DEFAULT_STEPS = 1;       // court.py:92
+    static constexpr bool HAS_VEC = false;
+    template <class C> static FIB_DEV const C &pinned(const C &k) { return k; }
     enum { iV, iNa_i, i_m, i_h, i_j, iK_i, i_oa, i_oi, i_ua, i_ui, i_xr, i_xs, iCa_i, i_d, i_f, i_f_Ca,
            iCa_rel, i_u, i_v, i_w, iCa_up };
     // MODE_FAST: the 4 fast_states (court.py:42,94-102); MODE_SLOW: the other 17 (court.py:103);
@@ -225,17 +299,6 @@ struct Courtemanche {
     template <class P>
     static FIB_DEV void calc_inter(float V, Inter &o)
     {
-        calc_inter_plain<P>(V, o);      // see BeelerReuter::step: no contraction where it buys nothing
-    }
-    template <class P>
-    static FIB_DEV void calc_inter_plain(float V, Inter &o)
-    {
-#include "court_inter.inc"
-    }
-    template <class P>
-    static FIB_DEV void calc_inter_fused(float V, Inter &o)
-    {
-#pragma clang fp contract(fast)
 #include "court_inter.inc"
     }
 
@@ -245,17 +308,6 @@ struct Courtemanche {
     template <class P, int MODE>
     static FIB_DEV void step(float (&s)[NVAR], float V, float lap, const Consts &k, int)
     {
-        step_plain<P, MODE>(s, V, lap, k);
-    }
-    template <class P, int MODE>
-    static FIB_DEV void step_plain(float (&s)[NVAR], float V, float lap, const Consts &k)
-    {
-#include "court_step.inc"
-    }
-    template <class P, int MODE>
-    static FIB_DEV void step_fused(float (&s)[NVAR], float V, float lap, const Consts &k)
-    {
-#pragma clang fp contract(fast)
 #include "court_step.inc"
     }
 };

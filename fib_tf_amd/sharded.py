@@ -266,9 +266,17 @@ def init_from_env():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # FIBTF_DIST_BACKEND=gloo + FIBTF_ONE_DEVICE=1 rehearse this path with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); production is always nccl = RCCL, one GPU per rank
+    backend = os.environ.get('FIBTF_DIST_BACKEND', 'nccl')
+    if os.environ.get('FIBTF_ONE_DEVICE') == '1':
+        local = 0
     torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
 

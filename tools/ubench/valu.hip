@@ -38,6 +38,15 @@ __global__ void k(float *out, unsigned long long *cyc, float a, float b)
                 x0 = __builtin_amdgcn_exp2f(x0); x1 = __builtin_amdgcn_exp2f(x1); x2 = __builtin_amdgcn_exp2f(x2); x3 = __builtin_amdgcn_exp2f(x3);
                 x4 = __builtin_amdgcn_exp2f(x4); x5 = __builtin_amdgcn_exp2f(x5); x6 = __builtin_amdgcn_exp2f(x6); x7 = __builtin_amdgcn_exp2f(x7);
             }
+        } else if (MODE == 6) {   // 2 independent chains, 16 instr / iter
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); }
+        } else if (MODE == 7) {   // 3 independent chains, 15 instr / iter
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); }
+        } else if (MODE == 8) {   // 4 independent chains, 16 instr / iter
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b); }
         } else if (MODE == 5) {   // cndmask / compare mix: 16 instr / iter
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -87,5 +96,8 @@ int main()
     run<3>("mul,add x8 independent", 16);
     run<4>("v_exp_f32 x8 independent", 16);
     run<5>("cmp+cndmask", 8);
+    run<6>("fma x2 chains", 16);
+    run<7>("fma x3 chains", 15);
+    run<8>("fma x4 chains", 16);
     return 0;
 }
