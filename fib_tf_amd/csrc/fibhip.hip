@@ -546,6 +546,7 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     c.ph.dpx = h->phase3 + h->cells;
     c.ph.q4 = h->phase3 + 2 * h->cells;
     c.ph.r4 = h->phase3 + 3 * h->cells;
+    c.ph.phi = h->phi_dev;
     c.consts = consts_of(h);
 }
 

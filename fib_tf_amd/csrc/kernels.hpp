@@ -58,6 +58,9 @@ struct PhaseTab {    // derived from ϕ once at set_phase (ionic.py:78-80)
     const float *dpx;   // ϕ[r,c+1] - ϕ[r,c-1]
     const float *q4;    // 4 * ϕ[r,c]
     const float *r4;    // RN(1 / q4): lets the division by 4ϕ run as a 3-instruction exact form
+    const float *phi;   // ϕ itself: one-sub-step launches stage a ϕ tile in LDS and difference it on the fly
+                        // (4 B per cell of traffic instead of 16; the K-fused kernels read the prepared arrays
+                        // once per K sub-steps and keep them in registers)
 };
 
 enum : unsigned {
@@ -101,7 +104,9 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
     constexpr int LP = CX + 2, LQ = CY + 2;                        // LDS tile (box + ring)
     constexpr int NC = CX * CY, CPT = (NC + NT - 1) / NT, NL = LP * LQ;
     constexpr unsigned WMASK = M::mask(MODE);
+    constexpr bool PHI_TILE = PHASE && K == 1;
     __shared__ float lds[(K > 1) ? 2 : 1][NL];
+    __shared__ float lphi[PHI_TILE ? NL : 1];
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;                                  // whole workgroup, before any barrier
@@ -123,6 +128,14 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         const float v = vin[(size_t)yy * g.W + xx];
         lds[0][i] = v;
         if (K > 1) lds[K > 1 ? 1 : 0][i] = v;
+        if (PHI_TILE) {                                            // ϕ is REFLECT-padded, not clamped (ionic.py:75-76)
+            int py = cy0 - 1 + ly + g.row_off, px = cx0 - 1 + lx;
+            py = py < 0 ? -py : (py > g.Hg - 1 ? 2 * (g.Hg - 1) - py : py);
+            px = px < 0 ? -px : (px > g.W - 1 ? 2 * (g.W - 1) - px : px);
+            py = clampi(py - g.row_off, 0, g.H - 1);
+            px = clampi(px, 0, g.W - 1);
+            lphi[i] = ph.phi[(size_t)py * g.W + px];
+        }
     }
 
     // ---- per-cell registers -------------------------------------------------------------------
@@ -142,7 +155,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         off[j] = clampi(gy, 0, g.H - 1) * g.W + clampi(gx, 0, g.W - 1);
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[j][v] = pt.in[v][off[j]];
-        if (PHASE) {
+        if (PHASE && !PHI_TILE) {
             pdy[j] = ph.dpy[off[j]];
             pdx[j] = ph.dpx[off[j]];
             pq4[j] = ph.q4[off[j]];
@@ -178,7 +191,12 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float NW = A[i - LP - 1], SW = A[i + LP - 1], NE = A[i - LP + 1], SE = A[i + LP + 1];
                 const float C = A[i];
                 float l = stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
-                if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
+                if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + phase_term, IEEE division
+                    const float dy = lphi[i + LP] - lphi[i - LP], dx = lphi[i + 1] - lphi[i - 1];
+                    l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);
+                } else if (PHASE) {
+                    l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
+                }
                 M::template step<P, MODE>(s[j], C, l, kk, sub0 + st);
             }
         }

@@ -1,0 +1,68 @@
+"""-m gpu: physics-level known answer.  The reference's only published physical measurement of this path is
+conduction velocity versus the diffusion coefficient (`diff_conduction_velcoty.dat:1-17`, measured with the
+two-electrode method of `egm.py:37-47`).  Its length unit per pixel is not recorded, so the comparison uses
+RATIOS of velocities, which are unit-free: CV(d) / CV(1.0).
+
+A planar S1 wave (the models' own define(s1=True)) runs along a 48 x 420 strip; the wavefront's arrival
+(linear interpolation of the upstroke crossing) is timed at two columns 150 px apart on the middle row.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# diff_conduction_velcoty.dat (cm/s)
+FENTON_CV = {0.5: 52.8, 0.7: 64.8, 1.0: 80.0, 1.5: 101.0}
+BR_CV = {0.5: 33.8, 1.0: 50.9, 1.5: 64.0, 2.0: 75.3}
+
+
+def velocity(model, thresh, x1=150, x2=300):
+    H = model.height
+    row = H // 2
+    t1 = t2 = None
+    prev = None
+    st = model._stepper
+    for i in model.run():
+        a, b = float(st.probe(0, row, x1)), float(st.probe(0, row, x2))
+        if prev is not None:
+            pa, pb = prev
+            if t1 is None and pa < thresh <= a:
+                t1 = i - 1 + (thresh - pa) / (a - pa)
+            if t2 is None and pb < thresh <= b:
+                t2 = i - 1 + (thresh - pb) / (b - pb)
+                break
+        prev = (a, b)
+    assert t1 is not None and t2 is not None, 'wavefront never reached the probes'
+    tick_ms = model.dt_per_step * model.dt
+    return (x2 - x1) / ((t2 - t1) * tick_ms)            # pixels per millisecond
+
+
+@pytest.mark.parametrize('policy', ['fast', 'exact'])
+def test_fenton_conduction_velocity_ratios(gpu_lib, policy):
+    from fib_tf_amd.fenton import Fenton4v
+    cv = {}
+    for d in FENTON_CV:
+        m = Fenton4v({'height': 48, 'width': 420, 'dt': 0.1, 'dt_per_plot': 10, 'diff': d, 'duration': 900,
+                      'fast_math': policy == 'fast'})
+        m.define()
+        cv[d] = velocity(m, 0.5)
+    for d in FENTON_CV:
+        got, want = cv[d] / cv[1.0], FENTON_CV[d] / FENTON_CV[1.0]
+        assert abs(got / want - 1.0) < 0.05, 'diff %.2f: CV ratio %.3f vs reference %.3f' % (d, got, want)
+    # and the reference's own fit VEL = 29 + 50*DIFF: slope/intercept ratio 50/29 within 15 %
+    ds = sorted(cv)
+    slope, icpt = np.polyfit(ds, [cv[d] for d in ds], 1)
+    assert abs((slope / icpt) / (50.0 / 29.0) - 1.0) < 0.15
+
+
+def test_br_conduction_velocity_ratios(gpu_lib):
+    from fib_tf_amd.br import BeelerReuter
+    cv = {}
+    for d in BR_CV:
+        m = BeelerReuter({'height': 48, 'width': 420, 'dt': 0.1, 'dt_per_plot': 10, 'diff': d, 'duration': 900,
+                          'cheby': True, 'skip': False})
+        m.define()
+        cv[d] = velocity(m, -40.0)
+    for d in BR_CV:
+        got, want = cv[d] / cv[1.0], BR_CV[d] / BR_CV[1.0]
+        assert abs(got / want - 1.0) < 0.05, 'diff %.2f: CV ratio %.3f vs reference %.3f' % (d, got, want)

@@ -25,7 +25,7 @@ void run_br(const char *name)
     g.ntiles = g.tiles_x * ((H + TY - 1) / TY);
     PtrTab<8> pt;
     for (int v = 0; v < 8; ++v) { pt.in[v] = buf + v * n; pt.out[v] = buf + (8 + v) * n; }
-    PhaseTab ph{buf + 16 * n, buf + 17 * n, buf + 18 * n, buf + 19 * n};
+    PhaseTab ph{buf + 16 * n, buf + 17 * n, buf + 18 * n, buf + 19 * n, buf + 18 * n};
     BeelerReuter::Consts k{};
     k.dt = 0.1f; k.ddt = 0.0809f; k.mdt = -0.1f; k.mdt_skip = -0.5f; k.skip = 0;
     constexpr int NW = (TY + 2 * (K - 1) + R - 1) / R;
@@ -61,7 +61,7 @@ void run(const char *name)
     g.ntiles = g.tiles_x * ((H + TY - 1) / TY);
     PtrTab<4> pt;
     for (int v = 0; v < 4; ++v) { pt.in[v] = buf + v * n; pt.out[v] = buf + (4 + v) * n; }
-    PhaseTab ph{buf + 8 * n, buf + 9 * n, buf + 10 * n, buf + 11 * n};
+    PhaseTab ph{buf + 8 * n, buf + 9 * n, buf + 10 * n, buf + 11 * n, buf + 10 * n};
     Fenton::Consts k{0.1f, 0.15f};
     constexpr int NW = (TY + 2 * (K - 1) + R - 1) / R;
     const int grid = ((g.ntiles + 7) / 8) * 8;
