@@ -60,6 +60,7 @@ def lib():
             'orc_fenton_run': [i, i, d, d, _fp, _fp, _fp, i],
             'orc_br_run': [i, i, d, d, _fp, _fp, i, _fp, _fp, i],
             'orc_court_run': [i, i, d, d, _fp, i, _fp, _fp, i, i, i],
+            'orc_court_ultra_run': [i, i, d, d, _fp, i, _fp, _fp, i],
         }
         for name, args in sig.items():
             fn = getattr(_lib, name)
@@ -172,6 +173,15 @@ def court_run(slab, dt, diff, phi, chronic, tick0, nticks, slow_every=10):
     _, H, W = slab.shape
     tmp = np.empty(23 * H * W, np.float32); phi = _phi(phi, H, W)
     lib().orc_court_run(H, W, dt, diff, _p(phi), int(chronic), _p(slab), _p(tmp), tick0, nticks, slow_every)
+    return slab
+
+
+def court_ultra_run(slab, dt, diff, phi, chronic, nticks):
+    """court_ultra.py schedule: every tick assigns all 21 variables with dt"""
+    assert slab.dtype == np.float32 and slab.flags.c_contiguous
+    _, H, W = slab.shape
+    tmp = np.empty(23 * H * W, np.float32); phi = _phi(phi, H, W)
+    lib().orc_court_ultra_run(H, W, dt, diff, _p(phi), int(chronic), _p(slab), _p(tmp), nticks)
     return slab
 
 

@@ -425,8 +425,19 @@ void orc_court_calc_inter(float V, float *out30)
 /* one solve(State), court.py:124-271: ALL 21 new values are produced (State1); the
  * caller picks the fast subset {V,Na_i,m,h} or the slow subset (court.py:94-103).
  * in/out: [21][H][W] in the insertion order of court.py:57-78.  scratch: 2*H*W.        */
+void orc_court_step_rate(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
+                         double slow_mult, const float *in, float *out, float *scratch);
+
 void orc_court_step(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
                     const float *in, float *out, float *scratch)
+{
+    orc_court_step_rate(H, W, dt, diff, phi, chronic_flag, 10.0, in, out, scratch);   /* court.py:122 */
+}
+
+/* slow_mult = 10: court.py (δt = 10·dt for the slow set, court.py:118-122);
+ * slow_mult = 1 : court_ultra.py (δt = dt for every variable, court_ultra.py:127-128)              */
+void orc_court_step_rate(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
+                         double slow_mult, const float *in, float *out, float *scratch)
 {
     const long n = (long)H * W;
     float *Va = scratch, *lap = scratch + n;
@@ -438,7 +449,7 @@ void orc_court_step(int H, int W, double dt, double diff, const float *phi, int 
     const double CSQN_max = 10, Km_CMDN = 0.00238, Km_TRPN = 0.0005, Km_CSQN = 0.8, V_cell = 20100;
     const double V_i = V_cell * 0.68, tau_f_Ca = 2.0, tau_u = 8.0, V_rel = 0.0048 * V_cell, V_up = 0.0552 * V_cell;
     const double chronic = chronic_flag ? 1.0 : 0.0;
-    const double dt_fast = dt, dt_slow = dt * 10;          /* δt(), court.py:118-122 */
+    const double dt_fast = dt, dt_slow = dt * slow_mult;   /* δt(), court.py:118-122 */
     const float mdt_f = F(-dt_fast), mdt_s = F(-dt_slow), dtf = F(dt_fast), dts = F(dt_slow);
     const float ddt = F(diff * dt_fast);
     const float em1_fCa = expm1f(F(-dt_slow / tau_f_Ca)), em1_u = expm1f(F(-dt_slow / tau_u));
@@ -588,6 +599,18 @@ void orc_set_threads(int n)
 #else
     (void)n;
 #endif
+}
+
+/* court_ultra.py:107-111: one solve per tick, all 21 variables assigned, single rate */
+void orc_court_ultra_run(int H, int W, double dt, double diff, const float *phi, int chronic, float *slab,
+                         float *tmp, int nticks)
+{
+    const long n = (long)H * W;
+    float *scr = tmp + COURT_NVAR * n;
+    for (int t = 0; t < nticks; ++t) {
+        orc_court_step_rate(H, W, dt, diff, phi, chronic, 1.0, slab, tmp, scr);
+        memcpy(slab, tmp, COURT_NVAR * n * sizeof(float));
+    }
 }
 
 int orc_num_threads(void)

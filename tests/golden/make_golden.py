@@ -38,6 +38,7 @@ import ionic                                        # noqa: E402,F401  (referenc
 import fenton                                       # noqa: E402  (reference)
 import br                                           # noqa: E402  (reference)
 import court                                        # noqa: E402  (reference)
+import court_ultra                                  # noqa: E402  (reference)
 
 T = tf.Tensor
 f32 = np.float32
@@ -343,7 +344,44 @@ def court_traj(name, H, W, diff, holes, ticks, snaps, s2=None):
     save(name, **out)
 
 
+def court_ultra_traj(name, H, W, diff, holes, ticks, snaps, s2=None):
+    """court_ultra.py: every tick assigns all variables with dt (court_ultra.py:107-111,127-128);
+    config['ultra_slow'] = False as in its own __main__ (court_ultra.py:543)"""
+    m = court_ultra.Courtemanche(cfg(H, W, diff, ultra_slow=False))
+    for h in holes:
+        m.add_hole_to_phase_field(*h)
+    out = {'phase': m.phase, 'diff': diff, 'dt': 0.1}
+    state = None
+    with np.errstate(all='ignore'):
+        for i in range(ticks):
+            m.defined = False
+            m.define(state=state)
+            var2name = {id(v): k for k, v in m._State.items()}
+            if i == 0:
+                state = {k: np.array(v.a) for k, v in m._State.items()}
+                for k, v in state.items():
+                    out['init_' + k] = v
+                names = list(m._State.keys())
+                assert len(m._ops['slow']) == 0
+            for var, new in m._ode_op:
+                state[var2name[id(var)]] = np.array(new.a)
+            if s2 is not None and i == s2[0]:
+                m._V = T(state['V'])
+                m.add_pace_op('s2', s2[1], s2[2])
+                state['V'] = np.array(m._ops['s2'][1].a)
+            if (i + 1) in snaps:
+                for k in names:
+                    out['%s_t%d' % (k, i + 1)] = np.array(state[k])
+    out['snap_ticks'] = np.array(sorted(snaps))
+    out['names'] = np.array(names)
+    save(name, **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'court_ultra':
+        court_ultra_traj('court_ultra_traj', 48, 56, 1.5, [(28, 24, 5), (28, 24, 22, True)], 120, {1, 10, 60, 120},
+                         s2=(50, 'luq', 10.0))
+        return
     unit_ops()
     fenton_step()
     br_step()
@@ -364,6 +402,8 @@ def main():
     court_traj('court_traj64', 64, 64, 0.809, [(32, 32, 6)], 300, {1, 2, 10, 11, 100, 300})
     court_traj('court_traj_ragged', 40, 56, 0.809, [(28, 20, 5), (28, 20, 24, True)], 60,
                {1, 11, 60}, s2=(30, 'luq', 10.0))
+    court_ultra_traj('court_ultra_traj', 48, 56, 1.5, [(28, 24, 5), (28, 24, 22, True)], 120, {1, 10, 60, 120},
+                     s2=(50, 'luq', 10.0))
 
 
 if __name__ == '__main__':

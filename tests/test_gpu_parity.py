@@ -434,3 +434,71 @@ def test_api_guards():
     m.defined = True
     with pytest.raises(AssertionError):
         m.add_hole_to_phase_field(8, 8, 2)       # after define, ionic.py:92-93
+
+
+# --------------------------------------------------------------------------------------------
+# court_ultra.py semantics: single rate, all variables every tick, checkpoint files
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('policy', POLICIES)
+def test_court_ultra_trajectory(gpu_lib, golden, policy, tmp_path):
+    from fib_tf_amd import court_ultra
+    f = golden('court_ultra_traj')
+    H, W = f['phase'].shape
+    m = court_ultra.Courtemanche(cfg(H, W, float(f['diff']), policy, ultra_slow=False))
+    m.phase = f['phase']
+    m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
+    for k in m.VAR_NAMES:
+        assert np.array_equal(m._State[k].eval(), f['init_' + k])
+    t0 = 0
+
+    def hook(i):
+        g = i + t0
+        if g % 10 == 0:
+            m.fire_op('slow')                      # an empty op in court_ultra.py: must change nothing
+        if g == 50:
+            m.fire_op('s2')
+
+    scales = {'V': 150.0, '_Ca_i_': 1e-3, '_Ca_rel_': 1.5}
+    for t in [int(x) for x in f['snap_ticks']]:
+        run_to(m, t - t0, hook)
+        t0 = t
+        for k in m.VAR_NAMES:
+            assert_close(m._State[k].eval(), f['%s_t%d' % (k, t)], 2e-5, 'court_ultra %s t%d' % (k, t),
+                         scale=scales.get(k, 1.0))
+    # checkpoint round trip in the reference's file format, then resume
+    m.duration = 1 * m.dt + 1e-9
+    for _ in m.run(keep_state=True):
+        pass
+    court_ultra.save_state(tmp_path / 'state_small', m.state)
+    st = court_ultra.load_state(tmp_path / 'state_small')
+    assert set(st) == set(m.VAR_NAMES)
+    m2 = court_ultra.Courtemanche(cfg(H, W, float(f['diff']), policy, ultra_slow=False))
+    m2.phase = f['phase']
+    m2.define(state=st)
+    for k in m.VAR_NAMES:
+        assert np.array_equal(m2._State[k].eval(), m.state[k])
+    with pytest.raises(NotImplementedError):
+        court_ultra.Courtemanche(cfg(H, W, 1.0, policy, ultra_slow=True))
+
+
+def test_run_with_screen_and_cycle_length_observer(gpu_lib, tmp_path):
+    """run(im): a frame every dt_per_plot sub-steps and the cycle-length detector at pixel
+    [20, width//2] (ionic.py:206-224), through the headless Screen"""
+    from fib_tf_amd.fenton import Fenton4v
+    from fib_tf_amd.screen import Screen
+    m = Fenton4v(cfg(64, 96, 1.5, 'fast', duration=120, dt_per_plot=20))
+    m.add_hole_to_phase_field(70, 40, 6)
+    m.define()
+    seen = []
+    m.cl_observer = lambda i, cl: seen.append((i, cl))
+    im = Screen(64, 96, 'test', keep=3)
+    ticks = [i for i in m.run(im, block=True)]
+    assert ticks == list(range(120))
+    assert im.count == 60                                           # every int(20/10) = 2 ticks
+    assert len(im.frames) == 3 and im.last.shape == (64, 96)
+    assert len(seen) == 1 and 10 < seen[0][0] < 100                 # the S1 front passes column 48 once
+    im.save(str(tmp_path / 'last.png'))
+    assert open(tmp_path / 'last.png', 'rb').read(8) == b'\x89PNG\r\n\x1a\n'
+    expect = m.image() * m.phase
+    assert np.abs(im.last - expect).max() < 0.2                     # last frame was taken 1 tick earlier

@@ -170,3 +170,21 @@ def test_golden_probe_values(golden):
     assert abs(float(b.mean()) - (-48.70845)) < 1e-4 and abs(float(b.max()) - 0.63488) < 1e-4
     c = golden('court_traj64')
     assert abs(float(c['V_t300'].mean()) - (-11.68459)) < 1e-4
+
+
+def test_court_ultra_trajectory(orc, golden):
+    """single-rate court_ultra.py schedule (all 21 variables every tick, dt)"""
+    from fib_tf_amd.ionic import IonicModel
+    f = golden('court_ultra_traj')
+    H, W = f['phase'].shape
+    rect = IonicModel({'height': H, 'width': W}).pace_rect('luq')
+    slab = np.stack([f['init_' + k] for k in orc.COURT_VARS]).copy()
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        for i in range(t0, t):
+            orc.court_ultra_run(slab, 0.1, float(f['diff']), f['phase'], True, 1)
+            if i == 50:
+                slab[0] = orc.pace(slab[0], *rect, 10.0, -100.0)
+        t0 = t
+        for i, k in enumerate(orc.COURT_VARS):
+            close(slab[i], f['%s_t%d' % (k, t)], 1e-5, {'V': 150.0, '_Ca_i_': 1e-3}.get(k, 1.0), 'ultra %s t%d' % (k, t))
