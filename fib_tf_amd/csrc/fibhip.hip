@@ -160,7 +160,8 @@ static const Variant g_variants[] = {
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
     S4(BeelerReuter, FIBHIP_BR, 0, 3, 58, 19, 2),
-    S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 18, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 19, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 19, 3),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
@@ -168,7 +169,8 @@ static const Variant g_variants[] = {
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
     S4(BeelerReuter, FIBHIP_BR, 1, 3, 58, 19, 2),
-    S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 18, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 19, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 19, 3),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 512),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),

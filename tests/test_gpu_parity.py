@@ -502,3 +502,81 @@ def test_run_with_screen_and_cycle_length_observer(gpu_lib, tmp_path):
     assert open(tmp_path / 'last.png', 'rb').read(8) == b'\x89PNG\r\n\x1a\n'
     expect = m.image() * m.phase
     assert np.abs(im.last - expect).max() < 0.2                     # last frame was taken 1 tick earlier
+
+
+# --------------------------------------------------------------------------------------------
+# edge cases: tiny / skinny grids, every kernel family, odd fusion plans
+# --------------------------------------------------------------------------------------------
+TINY = [(3, 3), (3, 9), (4, 7), (5, 5), (9, 3), (2050, 6), (6, 1300), (64, 63), (65, 129)]
+
+
+@pytest.mark.parametrize('shape', TINY, ids=['%dx%d' % s for s in TINY])
+def test_fenton_tiny_and_skinny_grids(gpu_lib, orc, shape, monkeypatch):
+    """3x3 is the smallest grid the reference's pads accept (interior of one cell: every tap clamps to it)"""
+    from fib_tf_amd.fenton import Fenton4v
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    st = np.stack([rng.uniform(-0.05, 1.05, (H, W)), rng.uniform(0, 1, (H, W)), rng.uniform(0, 1, (H, W)),
+                   rng.uniform(0, 1, (H, W))]).astype(np.float32)
+    phi = rng.uniform(0.2, 1.0, (H, W)).astype(np.float32)
+    ref = st.copy()
+    orc.fenton_run(ref, 0.1, 1.2, phi, 20)
+    for variant in ('', '1,64,4,256', '5,32,32,256', '10,32,32,512', '5,54,21,-3', '2,60,18,-4'):
+        if variant:
+            monkeypatch.setenv('FIBHIP_VARIANT', variant)
+        else:
+            monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+        m = Fenton4v(cfg(H, W, 1.2, 'exact'))
+        m.phase = phi
+        m.define(s1=False)
+        m._stepper.set_state(-1, st)
+        run_to(m, 2)
+        got = m._stepper.get_state()
+        assert_close(got, ref, 3e-6, 'fenton %dx%d [%s]' % (H, W, variant), scale=1.0)
+
+
+@pytest.mark.parametrize('spt', [1, 3, 7, 12])
+def test_custom_steps_per_tick(gpu_lib, orc, spt):
+    """steps_per_tick other than the reference's unroll factor: the launch plan mixes fusion depths
+    (e.g. 7 = 5 + 2) and must still equal `spt` plain sub-steps"""
+    from fib_tf_amd import _lib
+    H, W = 70, 90
+    rng = np.random.default_rng(spt)
+    st = np.stack([rng.uniform(-0.05, 1.05, (H, W)), rng.uniform(0, 1, (H, W)), rng.uniform(0, 1, (H, W)),
+                   rng.uniform(0, 1, (H, W))]).astype(np.float32)
+    phi = rng.uniform(0.2, 1.0, (H, W)).astype(np.float32)
+    s = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 0.9, steps_per_tick=spt)
+    s.set_state(-1, st)
+    s.set_phase(phi)
+    s.step(3)
+    got = s.get_state()
+    fused, launches = s.launch_plan()
+    assert fused <= max(spt, 1) and launches >= 1
+    ref = st.copy()
+    orc.fenton_run(ref, 0.1, 0.9, phi, 3 * spt)
+    assert_close(got, ref, 3e-6, 'spt=%d' % spt, scale=1.0)
+    s.close()
+
+
+def test_c_abi_argument_checks(gpu_lib):
+    from fib_tf_amd import _lib
+    with pytest.raises(_lib.FibhipError, match='at least 3x3'):
+        _lib.Stepper(_lib.FENTON4V, 2, 8, 0.1, 1.0)
+    with pytest.raises(_lib.FibhipError, match='unknown model'):
+        _lib.Stepper(9, 8, 8, 0.1, 1.0)
+    with pytest.raises(_lib.FibhipError, match='dt must be positive'):
+        _lib.Stepper(_lib.FENTON4V, 8, 8, 0.0, 1.0)
+    with pytest.raises(_lib.FibhipError, match='ghost'):
+        _lib.Stepper(_lib.FENTON4V, 30, 8, 0.1, 1.0, global_height=60, row_offset=10, ghost_top=4, ghost_bottom=4)
+    s = _lib.Stepper(_lib.BR, 8, 8, 0.1, 1.0, flags=_lib.CHEBY)
+    with pytest.raises(_lib.FibhipError, match='Chebyshev table not set'):
+        s.step(1)
+    with pytest.raises(_lib.FibhipError, match='108'):
+        s.set_consts(np.zeros(5, np.float32))
+    s.close()
+    c = _lib.Stepper(_lib.FENTON4V, 8, 8, 0.1, 1.0)
+    with pytest.raises(_lib.FibhipError, match='Courtemanche only'):
+        c.step_slow()
+    with pytest.raises(_lib.FibhipError, match='out of range'):
+        c.probe(0, 8, 0)
+    c.close()
