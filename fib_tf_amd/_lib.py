@@ -15,7 +15,7 @@ SRC = os.path.join(HERE, 'csrc', 'fibhip.hip')
 HDR = os.path.join(ROOT, 'include', 'fibhip.h')
 
 FENTON4V, BR, COURT = 0, 1, 2
-CHEBY, SKIP, CHRONIC, FAST, ALLVARS = 1, 2, 4, 8, 16
+CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED = 1, 2, 4, 8, 16, 32
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
                '-Wall', '-Wno-unused-value', '-Wno-unused-result']

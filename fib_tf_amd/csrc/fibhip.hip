@@ -195,6 +195,8 @@ struct fibhip_ctx {
     fibhip_desc d;
     int nvar, spt, mode;
     size_t cells;
+    int pitch;              // floats between rows of one state array (W planar, nvar*W row-interleaved)
+    size_t vstride;         // floats between the first rows of consecutive state arrays (cells / W)
     hipStream_t s0, s1;
     bool own_s0;
     float *slab[2];
@@ -342,6 +344,9 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
     h->nvar = nv;
     h->spt = desc->steps_per_tick > 0 ? desc->steps_per_tick : fibhip_default_steps_per_tick(desc->model);
     h->cells = (size_t)desc->height * desc->width;
+    const bool interleaved = (desc->flags & FIBHIP_ROW_INTERLEAVED) != 0;
+    h->pitch = interleaved ? nv * desc->width : desc->width;
+    h->vstride = interleaved ? (size_t)desc->width : h->cells;
     h->own0 = desc->ghost_top;
     h->own1 = desc->height - desc->ghost_bottom;
     h->mode = 0;
@@ -454,6 +459,7 @@ static Geo base_geo(const fibhip_ctx *h)
     Geo g;
     g.H = h->d.height;
     g.W = h->d.width;
+    g.pitch = h->pitch;
     g.Hg = h->d.global_height;
     g.row_off = h->d.row_offset;
     g.r0 = 0;
@@ -497,8 +503,9 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
     for (int v = v0; v < v1; ++v) {
         const float *s = src + (size_t)(v - v0) * h->cells;
         for (int b = 0; b < 2; ++b)               // both slabs, so either may become current
-            HIPCHK(hipMemcpyAsync(h->slab[b] + (size_t)v * h->cells, s, h->cells * sizeof(float),
-                                  hipMemcpyHostToDevice, h->s0));
+            HIPCHK(hipMemcpy2DAsync(h->slab[b] + (size_t)v * h->vstride, (size_t)h->pitch * sizeof(float), s,
+                                    (size_t)h->d.width * sizeof(float), (size_t)h->d.width * sizeof(float),
+                                    (size_t)h->d.height, hipMemcpyHostToDevice, h->s0));
     }
     HIPCHK(hipStreamSynchronize(h->s0));
     return 0;
@@ -511,8 +518,9 @@ extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
     for (int v = v0; v < v1; ++v)
-        HIPCHK(hipMemcpyAsync(dst + (size_t)(v - v0) * h->cells, h->slab[h->cur[v]] + (size_t)v * h->cells,
-                              h->cells * sizeof(float), hipMemcpyDeviceToHost, h->s0));
+        HIPCHK(hipMemcpy2DAsync(dst + (size_t)(v - v0) * h->cells, (size_t)h->d.width * sizeof(float),
+                                h->slab[h->cur[v]] + (size_t)v * h->vstride, (size_t)h->pitch * sizeof(float),
+                                (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
     HIPCHK(hipStreamSynchronize(h->s0));
     return 0;
 }
@@ -541,8 +549,8 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     for (int v = 0; v < h->nvar; ++v) {
         const bool flip = (v == 0) || (K > 1);
         nxt[v] = flip ? (cur[v] ^ 1) : cur[v];
-        c.in[v] = h->slab[cur[v]] + (size_t)v * h->cells;
-        c.out[v] = h->slab[nxt[v]] + (size_t)v * h->cells;
+        c.in[v] = h->slab[cur[v]] + (size_t)v * h->vstride;
+        c.out[v] = h->slab[nxt[v]] + (size_t)v * h->vstride;
     }
     c.ph.dpy = h->phase3;
     c.ph.dpx = h->phase3 + h->cells;
@@ -690,8 +698,8 @@ extern "C" int fibhip_step_slow(fibhip_t h)
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_slow inside an open tick");
     LaunchCtx c;
     for (int v = 0; v < h->nvar; ++v) {
-        c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->cells;
-        c.out[v] = h->slab[h->cur[v]] + (size_t)v * h->cells;     // in place
+        c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;
+        c.out[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;   // in place
     }
     c.consts = consts_of(h);
     c.g = base_geo(h);
@@ -711,7 +719,7 @@ extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, 
     NEED(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "pace inside an open tick");
     const Geo g = base_geo(h);
-    hipLaunchKernelGGL(pace_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->slab[h->cur[0]], r0, r1, c0, c1, v, min_v);
+    hipLaunchKernelGGL(pace_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->slab[h->cur[0]], r0, r1, c0, c1, v, min_v);   // variable 0 starts at the slab base in both layouts
     HIPCHK(hipGetLastError());
     h->launches++;
     return 0;
@@ -723,7 +731,7 @@ extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
     if (!out || var < 0 || var >= h->nvar || row < 0 || row >= h->d.height || col < 0 || col >= h->d.width)
         return fail(FIBHIP_EINVAL, "probe: out of range");
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "probe inside an open tick");
-    HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->cells + (size_t)row * h->d.width + col,
+    HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->vstride + (size_t)row * h->pitch + col,
                           sizeof(float), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(hipStreamSynchronize(h->s0));
     *out = *h->probe_host;
@@ -778,7 +786,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
         if (phi) {
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
-            g.H = g.Hg = H; g.W = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
+            g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
             hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
         }
         const float mdt = (float)(-dt);
@@ -798,7 +806,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
 extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
-    *dev_ptr = h->slab[h->cur[var]] + (size_t)var * h->cells;
+    *dev_ptr = h->slab[h->cur[var]] + (size_t)var * h->vstride;
     return h->cur[var];
 }
 
@@ -806,7 +814,7 @@ extern "C" int fibhip_next_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "next_ptr: bad argument");
     if (h->phase_of_tick == 0) return fail(FIBHIP_EINVAL, "next_ptr: no tick in flight");
-    *dev_ptr = h->slab[h->nxt[var]] + (size_t)var * h->cells;
+    *dev_ptr = h->slab[h->nxt[var]] + (size_t)var * h->vstride;
     return h->nxt[var];
 }
 

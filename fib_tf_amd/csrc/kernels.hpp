@@ -26,7 +26,10 @@
 namespace fib {
 
 struct Geo {
-    int H, W;        // rows / cols of this slab (pitch == W)
+    int H, W;        // rows / cols of this slab
+    int pitch;       // floats between consecutive rows of ONE state array: W for the planar slab
+                     // [nvar][H][W]; nvar*W for the row-interleaved slab [H][nvar][W] that row-block shards
+                     // use (there the g halo rows of all arrays are one contiguous block = one message)
     int Hg;          // rows of the whole grid
     int row_off;     // global row of local row 0
     int r0, r1;      // local rows [r0, r1) this launch computes and stores ...
@@ -125,7 +128,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         int yy = clampi(cy0 - 1 + ly + g.row_off, 1, g.Hg - 2) - g.row_off;
         yy = clampi(yy, 0, g.H - 1);                               // stay inside this slab
         const int xx = clampi(cx0 - 1 + lx, 1, g.W - 2);
-        const float v = vin[(size_t)yy * g.W + xx];
+        const float v = vin[(size_t)yy * g.pitch + xx];
         lds[0][i] = v;
         if (K > 1) lds[K > 1 ? 1 : 0][i] = v;
         if (PHI_TILE) {                                            // ϕ is REFLECT-padded, not clamped (ionic.py:75-76)
@@ -152,14 +155,16 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         li[j] = (cyy + 1) * LP + cxx + 1;
         const int gy = cy0 + cyy, gx = cx0 + cxx, gyg = gy + g.row_off;
         const bool indom = valid && gx >= 0 && gx < g.W && gyg >= 0 && gyg < g.Hg && gy >= 0 && gy < g.H;
-        off[j] = clampi(gy, 0, g.H - 1) * g.W + clampi(gx, 0, g.W - 1);
+        const int oy = clampi(gy, 0, g.H - 1), ox = clampi(gx, 0, g.W - 1);
+        off[j] = oy * g.pitch + ox;
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[j][v] = pt.in[v][off[j]];
         if (PHASE && !PHI_TILE) {
-            pdy[j] = ph.dpy[off[j]];
-            pdx[j] = ph.dpx[off[j]];
-            pq4[j] = ph.q4[off[j]];
-            pr4[j] = ph.r4[off[j]];
+            const int op = oy * g.W + ox;                          // the phase arrays are always planar
+            pdy[j] = ph.dpy[op];
+            pdx[j] = ph.dpx[op];
+            pq4[j] = ph.q4[op];
+            pr4[j] = ph.r4[op];
         }
         const bool border = gyg == 0 || gyg == g.Hg - 1 || gx == 0 || gx == g.W - 1;
         unsigned f = 0;
@@ -305,7 +310,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
         const int row = min(wave + q * NW, LQ - 1);
         int yy = clampi(cy0 - 1 + row + g.row_off, 1, g.Hg - 2) - g.row_off;
         yy = clampi(yy, 0, g.H - 1);
-        fv[q] = vin[(size_t)yy * g.W + xx];
+        fv[q] = vin[(size_t)yy * g.pitch + xx];
     }
 
     // ---- per-cell registers ---------------------------------------------------------------------
@@ -321,14 +326,16 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = cy0 + wave * R + r;
-        off[r] = clampi(gy, 0, g.H - 1) * g.W + clampi(gx, 0, g.W - 1);
+        const int oy = clampi(gy, 0, g.H - 1), ox = clampi(gx, 0, g.W - 1);
+        off[r] = oy * g.pitch + ox;
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
         if (PHASE) {
-            pdy[r] = ph.dpy[off[r]];
-            pdx[r] = ph.dpx[off[r]];
-            pq4[r] = ph.q4[off[r]];
-            pr4[r] = ph.r4[off[r]];
+            const int op = oy * g.W + ox;                           // the phase arrays are always planar
+            pdy[r] = ph.dpy[op];
+            pdx[r] = ph.dpx[op];
+            pq4[r] = ph.q4[op];
+            pr4[r] = ph.r4[op];
         }
     }
     // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
@@ -465,8 +472,8 @@ pointwise_kernel(Geo g, PtrTab<M::NVAR> pt, typename M::Consts k)
         int yy = clampi(gy + g.row_off, 1, g.Hg - 2) - g.row_off;
         yy = clampi(yy, 0, g.H - 1);
         const int xx = clampi(gx, 1, g.W - 2);
-        const float Vc = pt.in[0][(size_t)yy * g.W + xx];
-        const int o = gy * g.W + gx;
+        const float Vc = pt.in[0][(size_t)yy * g.pitch + xx];
+        const int o = gy * g.pitch + gx;
         float s[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[v] = pt.in[v][o];
@@ -533,9 +540,10 @@ __global__ void pace_kernel(Geo g, float *pot, int r0, int r1, int c0, int c1, f
 {
     const int n = g.H * g.W;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const int yg = e / g.W + g.row_off, x = e % g.W;
+        const int y = e / g.W, yg = y + g.row_off, x = e % g.W;
         const float sv = (yg >= r0 && yg < r1 && x >= c0 && x < c1) ? v : min_v;
-        pot[e] = fmaxf(pot[e], sv);
+        const size_t o = (size_t)y * g.pitch + x;
+        pot[o] = fmaxf(pot[o], sv);
     }
 }
 

@@ -57,13 +57,16 @@ class HipEngine:
         self.torch = torch
         self.dev = torch.device('cuda', device)
         nvar = _lib.check(_lib.lib().fibhip_nvar(model_id))
-        self.slabs = [torch.zeros((nvar, height, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        # row-interleaved slab [rows][nvar][width] (FIBHIP_ROW_INTERLEAVED): the g halo rows of ALL arrays
+        # are one contiguous block, i.e. one RCCL message per neighbour and direction
+        self.interleaved = True
+        self.slabs = [torch.zeros((height, nvar, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
         # a stream of our own (torch's default stream has the null handle, which fibhip reads as
         # "create one"): kernels, halo packing and RCCL's stream dependencies all hang off this one
         self.stream = torch.cuda.Stream(self.dev)
         torch.cuda.synchronize(self.dev)                    # the zero-fill above ran on the default stream
         stream = self.stream.cuda_stream
-        self.st = _lib.Stepper(model_id, height, width, dt, diff, flags=flags, device=device,
+        self.st = _lib.Stepper(model_id, height, width, dt, diff, flags=flags | _lib.ROW_INTERLEAVED, device=device,
                                steps_per_tick=steps_per_tick, global_height=global_height, row_offset=row_offset,
                                ghost_top=ghost_top, ghost_bottom=ghost_bottom, stream=stream,
                                ext_slabs=(self.slabs[0].data_ptr(), self.slabs[1].data_ptr()))
@@ -72,6 +75,10 @@ class HipEngine:
     # thin forwards
     def __getattr__(self, name):
         return getattr(self.st, name)
+
+    def var_view(self, idx, v):
+        """[rows, width] view of state array v in slab idx"""
+        return self.slabs[idx][:, v, :]
 
     def to_host(self, t):
         return t.detach().cpu().numpy()
@@ -128,8 +135,10 @@ class ShardedStepper:
         # rehearse this driver with several ranks on ONE GPU, and by the CPU tests) gets host staging.
         self.staged = dist.get_backend(group) != 'nccl'
         shape = (self.halo_n, self.g, width)
-        self.recv_up = torch.empty(shape, dtype=torch.float32) if self.staged and self.up is not None else None
-        self.recv_down = torch.empty(shape, dtype=torch.float32) if self.staged and self.down is not None else None
+        mk = (lambda: torch.empty(shape, dtype=torch.float32)) if self.staged else (lambda: self.eng.empty(shape))
+        self.recv_up = mk() if self.up is not None else None
+        self.recv_down = mk() if self.down is not None else None
+        self._op_cache = {}
         self.comm_s = 0.0
 
     # ---- data movement between the global arrays and this block ---------------------------------
@@ -165,45 +174,57 @@ class ShardedStepper:
     # ---- one tick ----------------------------------------------------------------------------------
     def _slab_view(self, var, nxt):
         idx, _ = self.eng.next_buf(var) if nxt else self.eng.state_buf(var)
-        return self.eng.slabs[idx][var]
+        return self.eng.var_view(idx, var)
 
     def _tick(self):
         with self.eng.stream_ctx():
             self._tick_on_stream()
+
+    def _p2p_ops(self, idx):
+        """RCCL fast path, cached per slab index: one contiguous [g, nvar, width] block each way"""
+        key = idx
+        if key not in self._op_cache:
+            dist, g, b = self.dist, self.g, self.gt + self.rows
+            slab, ops = self.eng.slabs[idx], []
+            if self.up is not None:
+                ops += [dist.P2POp(dist.isend, slab[self.gt:self.gt + g], self.up, self.group),
+                        dist.P2POp(dist.irecv, slab[:g], self.up, self.group)]
+            if self.down is not None:
+                ops += [dist.P2POp(dist.isend, slab[b - g:b], self.down, self.group),
+                        dist.P2POp(dist.irecv, slab[b:], self.down, self.group)]
+            self._op_cache[key] = ops
+        return self._op_cache[key]
 
     def _tick_on_stream(self):
         torch, dist, e, g = self.torch, self.dist, self.eng, self.g
         e.step_edges()
         t0 = time.perf_counter()
         b = self.gt + self.rows
-        if not self.staged:
-            # RCCL: every message is a contiguous g x W block of a slab — send straight out of the owned
-            # rows, receive straight into the ghost rows; all messages of the tick form one group.
-            ops = []
-            for v in range(self.halo_n):
-                a = self._slab_view(v, True)
-                if self.up is not None:
-                    ops += [dist.P2POp(dist.isend, a[self.gt:self.gt + g], self.up, self.group),
-                            dist.P2POp(dist.irecv, a[:g], self.up, self.group)]
-                if self.down is not None:
-                    ops += [dist.P2POp(dist.isend, a[b - g:b], self.down, self.group),
-                            dist.P2POp(dist.irecv, a[b:], self.down, self.group)]
+        idxs = {e.next_buf(v)[0] for v in range(self.halo_n)}
+        direct = (not self.staged and getattr(e, 'interleaved', False) and self.halo_n == self.nvar
+                  and len(idxs) == 1)
+        if direct:
+            ops = self._p2p_ops(next(iter(idxs)))
             reqs = dist.batch_isend_irecv(ops) if ops else []
             e.step_interior()                               # overlaps with the messages
             for r in reqs:
                 r.wait()
         else:
+            # general path: pack the halo rows of the exchanged arrays (they may sit in different slabs when
+            # sub-steps are launched one by one), optionally stage through the host (non-RCCL backends)
+            def dev(t):
+                return t.cpu() if self.staged else t
             ops, keep = [], []
             if self.up is not None:
-                s = torch.stack([self._slab_view(v, True)[self.gt:self.gt + g] for v in range(self.halo_n)]).cpu()
-                keep.append(s)
+                s = dev(torch.stack([self._slab_view(v, True)[self.gt:self.gt + g] for v in range(self.halo_n)]))
                 ops += [dist.P2POp(dist.isend, s, self.up, self.group),
                         dist.P2POp(dist.irecv, self.recv_up, self.up, self.group)]
-            if self.down is not None:
-                s = torch.stack([self._slab_view(v, True)[b - g:b] for v in range(self.halo_n)]).cpu()
                 keep.append(s)
+            if self.down is not None:
+                s = dev(torch.stack([self._slab_view(v, True)[b - g:b] for v in range(self.halo_n)]))
                 ops += [dist.P2POp(dist.isend, s, self.down, self.group),
                         dist.P2POp(dist.irecv, self.recv_down, self.down, self.group)]
+                keep.append(s)
             reqs = dist.batch_isend_irecv(ops) if ops else []
             e.step_interior()
             for r in reqs:

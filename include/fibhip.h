@@ -41,8 +41,12 @@ enum fibhip_flags {
     FIBHIP_CHRONIC = 1u << 2, /* COURT: self.chronic (court.py:41,167-170)                                */
     FIBHIP_FAST    = 1u << 3, /* hardware-rate division/exp/tanh instead of the rounding-faithful forms;  */
                               /* looser parity tolerance, see DESIGN.md                                    */
-    FIBHIP_ALLVARS = 1u << 4  /* COURT: every tick updates all 21 variables with dt (court_ultra.py:      */
+    FIBHIP_ALLVARS = 1u << 4, /* COURT: every tick updates all 21 variables with dt (court_ultra.py:      */
                               /* 107-111,127-128) instead of the fast/slow split                           */
+    FIBHIP_ROW_INTERLEAVED = 1u << 5 /* device slab layout [height][nvar][width] instead of               */
+                              /* [nvar][height][width]: the rows a row block exchanges with a neighbour    */
+                              /* (all arrays) are then ONE contiguous block.  Host-side get/set_state keep  */
+                              /* the planar [nvar][height][width] view.                                     */
 };
 
 enum fibhip_err {

@@ -121,6 +121,11 @@ class OracleEngine:
         return np.float32(self.slabs[self.cur][var, row, col].item())
 
     # -- HipEngine surface ---------------------------------------------------------------------
+    interleaved = False
+
+    def var_view(self, idx, v):
+        return self.slabs[idx][v]
+
     def to_host(self, t):
         return t.numpy()
 

@@ -21,7 +21,7 @@ void run_br(const char *name)
     for (size_t i = 0; i < n; ++i) h[i] = -80.f + 90.f * ((i * 2654435761u) % 1000) / 1000.f;       // V
     for (size_t i = n; i < 2 * n; ++i) h[i] = 1e-6f;                                                   // C
     hipMemcpy(buf, h.data(), 20 * n * sizeof(float), hipMemcpyHostToDevice);
-    Geo g{H, W, H, 0, 0, H, 0, 0, (H + TY - 1) / TY, (W + TX - 1) / TX, 0};
+    Geo g{H, W, W, H, 0, 0, H, 0, 0, (H + TY - 1) / TY, (W + TX - 1) / TX, 0};
     g.ntiles = g.tiles_x * ((H + TY - 1) / TY);
     PtrTab<8> pt;
     for (int v = 0; v < 8; ++v) { pt.in[v] = buf + v * n; pt.out[v] = buf + (8 + v) * n; }
@@ -57,7 +57,7 @@ void run(const char *name)
     std::vector<float> h(12 * n);
     for (size_t i = 0; i < 12 * n; ++i) h[i] = 0.3f + 0.4f * ((i * 2654435761u) % 1000) / 1000.f;
     hipMemcpy(buf, h.data(), 12 * n * sizeof(float), hipMemcpyHostToDevice);
-    Geo g{H, W, H, 0, 0, H, 0, 0, (H + TY - 1) / TY, (W + TX - 1) / TX, 0};
+    Geo g{H, W, W, H, 0, 0, H, 0, 0, (H + TY - 1) / TY, (W + TX - 1) / TX, 0};
     g.ntiles = g.tiles_x * ((H + TY - 1) / TY);
     PtrTab<4> pt;
     for (int v = 0; v < 4; ++v) { pt.in[v] = buf + v * n; pt.out[v] = buf + (4 + v) * n; }
