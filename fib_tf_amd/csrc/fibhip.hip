@@ -284,14 +284,24 @@ static int build_plan(fibhip_ctx *h)
     if (!prefK)
         if (const char *e = getenv("FIBHIP_K")) prefK = atoi(e);
     if (!prefK) {
-        // measured on MI355X (tuning table): a grid that gives each CU about one tile is
-        // launch/latency-bound and wants the deepest fusion; a grid with many tiles per CU is
-        // throughput-bound and wants the smaller redundant rim of a shallower one
-        const bool small = h->cells <= (size_t)1 << 20;
-        // Beeler-Reuter / Courtemanche spend their time in the transcendental pipe (64 / ~70 per
-        // cell-step), so redundant rim cells cost more than the launches they save: one sub-step
-        // per launch.  Fenton is cheap per cell: fuse.
-        prefK = (h->d.model != FIBHIP_FENTON4V) ? 1 : (small ? 10 : 5);
+        // Measured on MI355X (tools/sweep.py).  Beeler-Reuter / Courtemanche spend their time
+        // in the transcendental pipe (64 / ~70 per cell-step): redundant rim cells cost more than the
+        // launches they save, so one sub-step per launch.  Fenton is cheap per cell: fuse — as deep as the
+        // tick when the grid gives each CU about one tile (launch/latency-bound), 5 sub-steps with a
+        // smaller rim when there are many tiles per CU (throughput-bound), fatter waves when there are
+        // very many (occupancy).
+        prefK = 1;
+        if (h->d.model == FIBHIP_FENTON4V) {
+            const int rows = h->own1 - h->own0, W = h->d.width;
+            const long tiles10 = (long)((W + 43) / 44) * ((rows + 24) / 25);
+            const long tiles5 = (long)((W + 53) / 54) * ((rows + 20) / 21);
+            if (tiles10 <= 512) {
+                prefK = 10; want[0] = 44; want[1] = 25; want[2] = -3;
+            } else {
+                prefK = 5; want[0] = 54; want[1] = 21; want[2] = (tiles5 <= 2048) ? -3 : -4;
+            }
+            nwant = 1;
+        }
     }
     const int maxghost = (h->d.ghost_top > 0 || h->d.ghost_bottom > 0)
                              ? (h->d.ghost_top > 0 && h->d.ghost_bottom > 0
