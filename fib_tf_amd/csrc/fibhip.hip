@@ -323,9 +323,23 @@ static int build_plan(fibhip_ctx *h)
     return 0;
 }
 
+static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h);
+
 extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
 {
     if (!desc || !out) return fail(FIBHIP_EINVAL, "null argument");
+    fibhip_ctx *h = nullptr;
+    const int rc = create_impl(desc, h);
+    if (rc) {
+        if (h) fibhip_destroy(h);              // releases whatever had been acquired before the failure
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
+{
     if (desc->struct_size != (int)sizeof(fibhip_desc))
         return fail(FIBHIP_EINVAL, "fibhip_desc size mismatch: caller %d, library %d", desc->struct_size,
                     (int)sizeof(fibhip_desc));
@@ -347,7 +361,7 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
     if (desc->device < 0 || desc->device >= ndev) return fail(FIBHIP_EINVAL, "device %d out of range", desc->device);
     HIPCHK(hipSetDevice(desc->device));
 
-    fibhip_ctx *h = new (std::nothrow) fibhip_ctx();
+    h = new (std::nothrow) fibhip_ctx();
     if (!h) return fail(FIBHIP_ENOMEM, "out of host memory");
     h->d = *desc;
     h->d.global_height = Hg;
@@ -366,10 +380,8 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
     const int ming = (desc->ghost_top && desc->ghost_bottom)
                          ? (desc->ghost_top < desc->ghost_bottom ? desc->ghost_top : desc->ghost_bottom)
                          : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
-    if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt) {
-        delete h;
+    if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt)
         return fail(FIBHIP_EINVAL, "ghost width %d < steps_per_tick %d", ming, h->spt);
-    }
 
     // scalars: every Python-float product is formed in double and rounded once
     const double dt = desc->dt, diff = desc->diff;
@@ -417,13 +429,14 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
         h->slab[1] = (float *)desc->ext_slab[1];
         h->own_slab = false;
     } else {
+        h->own_slab = true;                       // before the loop: a partial allocation is still ours to free
         for (int i = 0; i < 2; ++i) {
             if (hipMalloc((void **)&h->slab[i], slab_bytes) != hipSuccess) {
+                h->slab[i] = nullptr;
                 return fail(FIBHIP_ENOMEM, "hipMalloc of %zu bytes failed", slab_bytes);
             }
             HIPCHK(hipMemsetAsync(h->slab[i], 0, slab_bytes, h->s0));
         }
-        h->own_slab = true;
     }
     HIPCHK(hipMalloc((void **)&h->phase3, 4 * h->cells * sizeof(float)));
     HIPCHK(hipMalloc((void **)&h->phi_dev, h->cells * sizeof(float)));
@@ -432,27 +445,21 @@ extern "C" int fibhip_create(const fibhip_desc *desc, fibhip_t *out)
     for (int v = 0; v < 21; ++v) h->cur[v] = h->nxt[v] = 0;
     h->phase_of_tick = 0;
     h->launches = 0;
-    const int rc = build_plan(h);
-    if (rc) {
-        fibhip_destroy(h);
-        return rc;
-    }
-    *out = h;
-    return 0;
+    return build_plan(h);
 }
 
 extern "C" int fibhip_destroy(fibhip_t h)
 {
     if (!h) return 0;
     hipSetDevice(h->d.device);
-    hipStreamSynchronize(h->s0);
+    if (h->s0) hipStreamSynchronize(h->s0);
     if (h->s1) hipStreamSynchronize(h->s1);
     if (h->own_slab) {
-        hipFree(h->slab[0]);
-        hipFree(h->slab[1]);
+        if (h->slab[0]) hipFree(h->slab[0]);
+        if (h->slab[1]) hipFree(h->slab[1]);
     }
-    hipFree(h->phase3);
-    hipFree(h->phi_dev);
+    if (h->phase3) hipFree(h->phase3);
+    if (h->phi_dev) hipFree(h->phi_dev);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->ev_main) hipEventDestroy(h->ev_main);
     if (h->ev_int) hipEventDestroy(h->ev_int);
