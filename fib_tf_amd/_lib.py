@@ -61,6 +61,7 @@ SYMBOLS = {
     'fibhip_state_ptr': ([_h, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_next_ptr': ([_h, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_halo_vars': ([_h], C.c_int),
+    'fibhip_halo_due': ([_h], C.c_int),
     'fibhip_unit_op': ([C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_double, C.c_int, _fp],
                        C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
@@ -220,6 +221,9 @@ class Stepper:
 
     def halo_vars(self):
         return check(self._L.fibhip_halo_vars(self._h))
+
+    def halo_due(self):
+        return bool(check(self._L.fibhip_halo_due(self._h)))
 
     def launch_plan(self):
         k, n = C.c_int(), C.c_int()

@@ -215,6 +215,8 @@ struct fibhip_ctx {
     int phase_of_tick;      // 0 idle, 1 edges issued, 2 interior issued
     long launches;
     int own0, own1;         // owned local rows
+    int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
+                            // cpos = ticks done since the last exchange
     float *probe_host;      // pinned
 };
 
@@ -382,6 +384,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
                          : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
     if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt)
         return fail(FIBHIP_EINVAL, "ghost width %d < steps_per_tick %d", ming, h->spt);
+    h->cycle = (desc->ghost_top || desc->ghost_bottom) ? ming / h->spt : 1;
+    h->cpos = 0;
 
     // scalars: every Python-float product is formed in double and rounded once
     const double dt = desc->dt, diff = desc->diff;
@@ -525,6 +529,7 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
                                     (size_t)h->d.height, hipMemcpyHostToDevice, h->s0));
     }
     HIPCHK(hipStreamSynchronize(h->s0));
+    h->cpos = 0;                                  // the caller supplied fresh ghost rows too
     return 0;
 }
 
@@ -597,9 +602,18 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 
 // rows launch `l` of the plan has to produce: the owned rows grown by the sub-steps still to come
 // (those rows are the halo of the later launches of the same tick), clipped to the slab
+// Communication-avoiding ghost zone: with ghost = cycle * steps_per_tick rows the neighbours' rows are
+// exchanged only every `cycle` ticks; tick j of a cycle also advances the (cycle-1-j) * spt ghost rows
+// next to the owned block, which are the halo of the ticks still to come.
+static inline int ext_rows(const fibhip_ctx *h) { return (h->cycle - 1 - h->cpos) * h->spt; }
+static inline bool ends_cycle(const fibhip_ctx *h)
+{
+    return (h->d.ghost_top || h->d.ghost_bottom) && h->cpos == h->cycle - 1;
+}
+
 static void rows_of_launch(const fibhip_ctx *h, size_t l, int &r0, int &r1)
 {
-    int rem = 0;
+    int rem = ext_rows(h);
     for (size_t m = l + 1; m < h->plan.size(); ++m) rem += h->plan[m].K;
     r0 = imax(0, h->own0 - (h->d.ghost_top ? rem : 0));
     r1 = imin(h->d.height, h->own1 + (h->d.ghost_bottom ? rem : 0));
@@ -633,11 +647,11 @@ extern "C" int fibhip_step_edges(fibhip_t h)
             sub += it.K;
             continue;
         }
-        // last launch: only the strips a neighbour is waiting for
-        const int hw = imax(h->d.ghost_top, h->d.ghost_bottom);
+        // last launch: only the strips a neighbour is waiting for — and only on the tick that ends a cycle
+        const int hw = ends_cycle(h) ? imax(h->d.ghost_top, h->d.ghost_bottom) : 0;
         const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
-        int t1 = h->d.ghost_top ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
-        int b0 = h->d.ghost_bottom ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
+        int t1 = (hw && h->d.ghost_top) ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
+        int b0 = (hw && h->d.ghost_bottom) ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
         if (int rc = launch_range(h, h->s0, it, c, r0, t1, b0, r1)) return rc;   // both strips, one launch
         memcpy(h->nxt, nxt, sizeof nxt);
     }
@@ -667,11 +681,11 @@ extern "C" int fibhip_step_interior(fibhip_t h)
     c.sub0 = sub;
     int r0, r1;
     rows_of_launch(h, h->plan.size() - 1, r0, r1);
-    const int hw = imax(h->d.ghost_top, h->d.ghost_bottom);
+    const bool split = ends_cycle(h);
+    const int hw = split ? imax(h->d.ghost_top, h->d.ghost_bottom) : 0;
     const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
-    const int t1 = h->d.ghost_top ? imin(r0 + e, r1) : r0;
-    const int b0 = h->d.ghost_bottom ? imax(r1 - e, t1) : r1;
-    const bool split = (h->d.ghost_top || h->d.ghost_bottom);
+    const int t1 = (hw && h->d.ghost_top) ? imin(r0 + e, r1) : r0;
+    const int b0 = (hw && h->d.ghost_bottom) ? imax(r1 - e, t1) : r1;
     hipStream_t st = split ? h->s1 : h->s0;
     if (split) {
         // the interior reads what the earlier launches of this tick (and the previous tick's halo
@@ -689,8 +703,9 @@ extern "C" int fibhip_step_commit(fibhip_t h)
 {
     NEED(h);
     if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
-    if (h->d.ghost_top || h->d.ghost_bottom) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
+    if (ends_cycle(h)) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
     memcpy(h->cur, h->nxt, sizeof h->cur);
+    h->cpos = (h->cpos + 1) % h->cycle;
     h->phase_of_tick = 0;
     return 0;
 }
@@ -720,8 +735,10 @@ extern "C" int fibhip_step_slow(fibhip_t h)
     }
     c.consts = consts_of(h);
     c.g = base_geo(h);
-    c.g.r0 = h->own0;
-    c.g.r1 = h->own1;
+    // the ghost rows that later ticks of this cycle still advance must get the slow update too
+    const int live = (h->cpos == 0 ? h->cycle : h->cycle - h->cpos) * h->spt;
+    c.g.r0 = imax(0, h->own0 - (h->d.ghost_top ? live : 0));
+    c.g.r1 = imin(h->d.height, h->own1 + (h->d.ghost_bottom ? live : 0));
     c.sub0 = 0;
     const bool fast = (h->d.flags & FIBHIP_FAST) != 0;
     launch_fn slow_fn = fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
@@ -838,7 +855,13 @@ extern "C" int fibhip_next_ptr(fibhip_t h, int var, void **dev_ptr)
 extern "C" int fibhip_halo_vars(fibhip_t h)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
-    return h->spt > 1 ? h->nvar : 1;
+    return (h->spt > 1 || h->cycle > 1) ? h->nvar : 1;
+}
+
+extern "C" int fibhip_halo_due(fibhip_t h)
+{
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    return ends_cycle(h) ? 1 : 0;
 }
 
 extern "C" int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick)

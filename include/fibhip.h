@@ -71,7 +71,10 @@ typedef struct fibhip_desc {
     int global_height;   /* rows of the whole grid; 0 = height                                            */
     int row_offset;      /* global row index of local row 0                                               */
     int ghost_top;       /* rows at the top of the slab that mirror the upper neighbour's rows            */
-    int ghost_bottom;    /* same at the bottom; a ghost width must be >= steps_per_tick                   */
+    int ghost_bottom;    /* same at the bottom; a ghost width must be >= steps_per_tick.  A width of      */
+                         /* m * steps_per_tick makes the halo exchange due only every m-th tick           */
+                         /* (fibhip_halo_due): the ticks in between also advance the ghost rows they      */
+                         /* still need (communication-avoiding, redundant compute instead of messages)    */
     void *stream;        /* hipStream_t to enqueue on (e.g. the caller's torch stream); NULL = own stream */
     void *ext_slab[2];   /* optional caller-owned DEVICE slabs, each nvar*height*width floats             */
                          /* (so that the caller can hand them to RCCL); NULL = library allocates          */
@@ -136,6 +139,10 @@ int fibhip_next_ptr(fibhip_t h, int var, void **dev_ptr);
 /* number of state arrays whose ghost rows must be refreshed after each tick (all of them when a tick
  * fuses several sub-steps, only the potential when steps_per_tick == 1)                                 */
 int fibhip_halo_vars(fibhip_t h);
+/* 1 if the tick that is open (or, between ticks, the next one) ends an exchange cycle: the caller must then
+ * refresh ALL ghost rows of the fibhip_halo_vars arrays between step_edges and step_commit; 0 otherwise
+ * (step_edges launches everything, step_interior nothing, no exchange)                                    */
+int fibhip_halo_due(fibhip_t h);
 
 /* IonicModel's public building blocks as stand-alone array ops on HOST arrays [H*W] (unit-level parity):
  * op 0 = enforce_boundary(a)            ionic.py:107-113

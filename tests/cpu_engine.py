@@ -36,6 +36,9 @@ class OracleEngine:
         self.slabs = [torch.zeros((n, height, width), dtype=torch.float32) for _ in range(2)]
         self.cur, self.open = 0, False
         self.phi, self.cheb = None, None
+        ghosts = [x for x in (ghost_top, ghost_bottom) if x]
+        self.cycle = (min(ghosts) // steps_per_tick) if ghosts else 1
+        self.cpos = 0
 
     # -- Stepper surface -----------------------------------------------------------------------
     def set_phase(self, phi):
@@ -57,7 +60,10 @@ class OracleEngine:
         self.cheb = np.ascontiguousarray(tbl, np.float32).reshape(12, 9)
 
     def halo_vars(self):
-        return NVAR[self.model] if self.spt > 1 else 1
+        return NVAR[self.model] if (self.spt > 1 or self.cycle > 1) else 1
+
+    def halo_due(self):
+        return bool(self.gt or self.gb) and self.cpos == self.cycle - 1
 
     def launch_plan(self):
         return self.spt, 1
@@ -97,6 +103,7 @@ class OracleEngine:
 
     def step_commit(self):
         self.cur ^= 1
+        self.cpos = (self.cpos + 1) % self.cycle
         self.open = False
 
     def step_slow(self):

@@ -22,7 +22,8 @@ def run_case(rank, world, port, case, outdir):
         from fib_tf_amd.court import Courtemanche
         H, W, ticks = case['H'], case['W'], case['ticks']
         cfg = {'height': H, 'width': W, 'dt': 0.1, 'dt_per_plot': 10, 'diff': case['diff'], 'duration': 1000,
-               'cheby': case.get('cheby', False), 'skip': case.get('skip', False)}
+               'cheby': case.get('cheby', False), 'skip': case.get('skip', False),
+               'halo_ticks': case.get('halo_ticks', 4)}
         if case.get('engine', 'oracle') == 'oracle':
             cfg['engine_factory'] = OracleEngine         # CPU rehearsal; otherwise the HIP engine on device 0
         else:
@@ -45,7 +46,7 @@ def run_case(rank, world, port, case, outdir):
         img = m.image()
         if rank == 0:
             np.savez(os.path.join(outdir, 'out.npz'), full=full, img=img, trend=np.array(trend, np.float32),
-                     blocks=np.array(m._stepper.blocks))
+                     blocks=np.array(m._stepper.blocks), halo_ticks=m._stepper.halo_ticks)
     finally:
         dist.barrier()
         dist.destroy_process_group()

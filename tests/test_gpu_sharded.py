@@ -22,6 +22,14 @@ CASES = [
     (3, {'model': 'br', 'H': 100, 'W': 64, 'diff': 0.809, 'hole': (30, 40, 8), 'ticks': 6, 's2': 3, 'amp': 10.0,
          'cheby': False, 'skip': True}),
     (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 25, 's2': 12, 'amp': 10.0}),
+    (2, {'model': 'fenton', 'H': 128, 'W': 96, 'diff': 1.5, 'hole': (40, 64, 9), 'ticks': 9, 's2': 5, 'amp': 1.0,
+         'halo_ticks': 1}),
+    (2, {'model': 'fenton', 'H': 300, 'W': 96, 'diff': 1.5, 'hole': (40, 150, 9), 'ticks': 11, 's2': 5, 'amp': 1.0,
+         'halo_ticks': 4}),
+    (3, {'model': 'br', 'H': 120, 'W': 64, 'diff': 0.809, 'hole': (30, 40, 8), 'ticks': 7, 's2': 3, 'amp': 10.0,
+         'cheby': True, 'skip': True, 'halo_ticks': 2}),
+    (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 23, 's2': 12, 'amp': 10.0,
+         'halo_ticks': 1}),
 ]
 
 
@@ -47,7 +55,8 @@ def single(case):
     return np.stack([m._State[n].eval() for n in m.VAR_NAMES]), np.array(trend, np.float32)
 
 
-@pytest.mark.parametrize('world,case', CASES, ids=['%s-x%d' % (c['model'], w) for w, c in CASES])
+@pytest.mark.parametrize('world,case', CASES,
+                         ids=['%s-x%d-h%s' % (c['model'], w, c.get('halo_ticks', 'd')) for w, c in CASES])
 def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path):
     want, trend = single(case)
     out = launch(world, dict(case, engine='hip'), tmp_path)

@@ -90,10 +90,18 @@ CASES = [
     (3, {'model': 'br', 'H': 33, 'W': 25, 'diff': 0.809, 'hole': (10, 15, 4), 'ticks': 6, 's2': 2, 'amp': 10.0,
          'cheby': False, 'skip': True}),
     (2, {'model': 'court', 'H': 60, 'W': 56, 'diff': 0.809, 'hole': (28, 30, 5), 'ticks': 25, 's2': 12, 'amp': 10.0}),
+    # one exchange per tick (halo_ticks=1) and a ghost zone 3 ticks deep with a tick count that is not a multiple
+    (2, {'model': 'fenton', 'H': 80, 'W': 40, 'diff': 1.5, 'hole': (20, 40, 5), 'ticks': 5, 's2': 2, 'amp': 1.0,
+         'halo_ticks': 1}),
+    (2, {'model': 'fenton', 'H': 80, 'W': 40, 'diff': 1.5, 'hole': (20, 40, 5), 'ticks': 7, 's2': 4, 'amp': 1.0,
+         'halo_ticks': 3}),
+    (3, {'model': 'court', 'H': 45, 'W': 56, 'diff': 0.809, 'hole': (28, 20, 5), 'ticks': 23, 's2': 11, 'amp': 10.0,
+         'halo_ticks': 1}),
 ]
 
 
-@pytest.mark.parametrize('world,case', CASES, ids=['%s-x%d' % (c['model'], w) for w, c in CASES])
+@pytest.mark.parametrize('world,case', CASES,
+                         ids=['%s-x%d-h%s' % (c['model'], w, c.get('halo_ticks', 'd')) for w, c in CASES])
 def test_sharded_equals_single_domain(world, case, tmp_path, orc):
     out = launch(world, case, tmp_path)
     want, trend = single_domain(case, orc)
