@@ -138,6 +138,7 @@ struct Variant {
 static const Variant g_variants[] = {
     // ---- Fenton 4v ----
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 6),
@@ -188,7 +189,7 @@ static const int g_nvariants = (int)(sizeof g_variants / sizeof g_variants[0]);
 struct PlanItem {
     int K;
     launch_fn fn;
-    int TY;
+    int TY, TX;
 };
 
 struct fibhip_ctx {
@@ -215,6 +216,7 @@ struct fibhip_ctx {
     int phase_of_tick;      // 0 idle, 1 edges issued, 2 interior issued
     long launches;
     int own0, own1;         // owned local rows
+    bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
                             // cpos = ticks done since the last exchange
     float *probe_host;      // pinned
@@ -294,11 +296,18 @@ static int build_plan(fibhip_ctx *h)
         // very many (occupancy).
         prefK = 1;
         if (h->d.model == FIBHIP_FENTON4V) {
-            const int rows = h->own1 - h->own0, W = h->d.width;
+            // rows of the largest launch: the first tick of an exchange cycle also advances the ghost rows
+            const int ext = (h->cycle - 1) * h->spt;
+            const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
+            const int W = h->d.width;
             const long tiles10 = (long)((W + 43) / 44) * ((rows + 24) / 25);
             const long tiles5 = (long)((W + 53) / 54) * ((rows + 20) / 21);
             if (tiles10 <= 512) {
-                prefK = 10; want[0] = 44; want[1] = 25; want[2] = -3;
+                // a K=10 tile is latency-bound (~20 us however few there are): never let the tile count spill
+                // just past one round of 256 CUs — take the taller tile instead
+                const long t28 = (long)((W + 43) / 44) * ((rows + 27) / 28);
+                const bool taller = tiles10 > 256 && t28 <= 256;
+                prefK = 10; want[0] = 44; want[1] = taller ? 28 : 25; want[2] = -3;
             } else {
                 prefK = 5; want[0] = 54; want[1] = 21; want[2] = (tiles5 <= 2048) ? -3 : -4;
             }
@@ -319,7 +328,7 @@ static int build_plan(fibhip_ctx *h)
             if (!best && nwant) best = find_variant(h, K, nullptr);
         }
         if (!best) return fail(FIBHIP_EINVAL, "no kernel variant for model %d mode %d", h->d.model, h->mode);
-        h->plan.push_back({best->K, best->fn, best->TY});
+        h->plan.push_back({best->K, best->fn, best->TY, best->TX});
         rem -= best->K;
     }
     return 0;
@@ -610,6 +619,20 @@ static inline bool ends_cycle(const fibhip_ctx *h)
 {
     return (h->d.ghost_top || h->d.ghost_bottom) && h->cpos == h->cycle - 1;
 }
+// On the tick that ends a cycle the strips the neighbours wait for can be launched first (main stream) and
+// the rest of the block on a second stream, so that the messages overlap the interior.  A fused launch is
+// latency-bound (~20 us however few tiles it has; measured: the split costs a 512-row block 44 us per tick
+// instead of 22), so it only pays when the interior is several rounds of CUs long.
+static inline bool split_tick(const fibhip_ctx *h, const PlanItem &it)
+{
+    if (!ends_cycle(h)) return false;
+    if (const char *e = getenv("FIBHIP_SPLIT")) return atoi(e) != 0;
+    const int hw = imax(h->d.ghost_top, h->d.ghost_bottom);
+    const int edge = ((hw + it.TY - 1) / it.TY) * it.TY;
+    const long interior_rows = (long)(h->own1 - h->own0) - ((h->d.ghost_top ? edge : 0) + (h->d.ghost_bottom ? edge : 0));
+    const long tiles = ((h->d.width + it.TX - 1) / it.TX) * ((interior_rows + it.TY - 1) / it.TY);
+    return interior_rows > 0 && tiles >= 4 * 256;
+}
 
 static void rows_of_launch(const fibhip_ctx *h, size_t l, int &r0, int &r1)
 {
@@ -647,12 +670,21 @@ extern "C" int fibhip_step_edges(fibhip_t h)
             sub += it.K;
             continue;
         }
-        // last launch: only the strips a neighbour is waiting for — and only on the tick that ends a cycle
-        const int hw = ends_cycle(h) ? imax(h->d.ghost_top, h->d.ghost_bottom) : 0;
-        const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
-        int t1 = (hw && h->d.ghost_top) ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
-        int b0 = (hw && h->d.ghost_bottom) ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
-        if (int rc = launch_range(h, h->s0, it, c, r0, t1, b0, r1)) return rc;   // both strips, one launch
+        // last launch: only the strips a neighbour is waiting for — and only on the tick that ends a cycle.
+        // The interior part (step_interior, second stream) depends on everything enqueued on s0 up to HERE
+        // — the earlier launches of this tick and the previous tick's halo refresh — but not on the strips.
+        const bool split = split_tick(h, it);
+        h->whole_in_edges = ends_cycle(h) && !split;      // the caller exchanges right after step_edges:
+        if (h->whole_in_edges) {                          // everything it sends must be computed by then
+            if (int rc = launch_range(h, h->s0, it, c, r0, r1)) return rc;
+        } else {
+            if (split) HIPCHK(hipEventRecord(h->ev_main, h->s0));
+            const int hw = split ? imax(h->d.ghost_top, h->d.ghost_bottom) : 0;
+            const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
+            int t1 = (hw && h->d.ghost_top) ? imin(r0 + e, r1) : r0;          // top strip [r0, t1)
+            int b0 = (hw && h->d.ghost_bottom) ? imax(r1 - e, t1) : r1;        // bottom strip [b0, r1)
+            if (int rc = launch_range(h, h->s0, it, c, r0, t1, b0, r1)) return rc;   // both strips, one launch
+        }
         memcpy(h->nxt, nxt, sizeof nxt);
     }
     h->phase_of_tick = 1;
@@ -663,6 +695,10 @@ extern "C" int fibhip_step_interior(fibhip_t h)
 {
     NEED(h);
     if (h->phase_of_tick != 1) return fail(FIBHIP_EINVAL, "step_interior: call step_edges first");
+    if (h->whole_in_edges) {                              // step_edges already launched the whole block
+        h->phase_of_tick = 2;
+        return 0;
+    }
     // recompute the last launch's geometry (same arithmetic as step_edges)
     int cur[21];
     memcpy(cur, h->cur, sizeof cur);
@@ -681,18 +717,13 @@ extern "C" int fibhip_step_interior(fibhip_t h)
     c.sub0 = sub;
     int r0, r1;
     rows_of_launch(h, h->plan.size() - 1, r0, r1);
-    const bool split = ends_cycle(h);
+    const bool split = split_tick(h, it);
     const int hw = split ? imax(h->d.ghost_top, h->d.ghost_bottom) : 0;
     const int e = hw > 0 ? ((hw + it.TY - 1) / it.TY) * it.TY : 0;
     const int t1 = (hw && h->d.ghost_top) ? imin(r0 + e, r1) : r0;
     const int b0 = (hw && h->d.ghost_bottom) ? imax(r1 - e, t1) : r1;
     hipStream_t st = split ? h->s1 : h->s0;
-    if (split) {
-        // the interior reads what the earlier launches of this tick (and the previous tick's halo
-        // exchange, which the caller ordered on s0) produced
-        HIPCHK(hipEventRecord(h->ev_main, h->s0));
-        HIPCHK(hipStreamWaitEvent(h->s1, h->ev_main, 0));
-    }
+    if (split) HIPCHK(hipStreamWaitEvent(h->s1, h->ev_main, 0));   // recorded in step_edges, before the strips
     if (int rc = launch_range(h, st, it, c, t1, b0)) return rc;
     if (split) HIPCHK(hipEventRecord(h->ev_int, h->s1));
     h->phase_of_tick = 2;
@@ -703,7 +734,7 @@ extern "C" int fibhip_step_commit(fibhip_t h)
 {
     NEED(h);
     if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
-    if (ends_cycle(h)) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
+    if (split_tick(h, h->plan.back())) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
     memcpy(h->cur, h->nxt, sizeof h->cur);
     h->cpos = (h->cpos + 1) % h->cycle;
     h->phase_of_tick = 0;

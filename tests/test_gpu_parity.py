@@ -178,7 +178,7 @@ def run_to(model, ticks, hook=None):
             hook(i)
 
 
-FENTON_VARIANTS = ['', '10,44,25,-4', '10,44,25,-3', '10,44,25,-5', '10,44,25,-6', '10,44,32,-4', '5,54,21,-4',
+FENTON_VARIANTS = ['', '10,44,28,-3', '10,44,25,-4', '10,44,25,-3', '10,44,25,-5', '10,44,25,-6', '10,44,32,-4', '5,54,21,-4',
                    '5,54,21,-3', '5,54,32,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512',
                    '5,32,16,256', '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256']
 

@@ -57,7 +57,14 @@ def single(case):
 
 @pytest.mark.parametrize('world,case', CASES,
                          ids=['%s-x%d-h%s' % (c['model'], w, c.get('halo_ticks', 'd')) for w, c in CASES])
-def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path):
+@pytest.mark.parametrize('split', ['auto', 'split'])
+def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split, monkeypatch):
+    """split: force the two-stream edge-strips / interior launch on every exchange tick (the library only
+    chooses it by itself for blocks that are several CU rounds tall)"""
+    if split == 'split':
+        monkeypatch.setenv('FIBHIP_SPLIT', '1')
+    else:
+        monkeypatch.delenv('FIBHIP_SPLIT', raising=False)
     want, trend = single(case)
     out = launch(world, dict(case, engine='hip'), tmp_path)
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
