@@ -138,6 +138,9 @@ def bench_single(args):
                 m.fire_op('s2')
             tick += 1
 
+    st.step(1)                                        # setup, not a warm-up step: loads the code object
+    st.sync()
+    tick = 1
     advance(args.warmup)
     st.sync()
     t0 = time.perf_counter()

@@ -335,6 +335,8 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                 m.fire_op('s2')
             tick += 1
 
+    advance(st.halo_ticks)                              # setup, not warm-up: one full exchange cycle creates
+    st.sync()                                           # the RCCL channels and loads the code objects
     advance(args.warmup)
     st.sync()
     dist.barrier()
