@@ -1,0 +1,104 @@
+"""-m gpu: parity at BASELINE.json's FULL sizes (configs[1], [2], [4]) and size-independent properties.
+
+The oracle runs the same workload on the host cores (a second or two each); beyond that, the checks use
+properties that hold at any size: a launch plan must never change a bit of the result (fusion depth,
+tile shape, kernel family), and a mirror-symmetric problem must stay mirror-symmetric.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASE = {'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'skip': False, 'cheby': True}
+
+
+def state(m):
+    return np.stack([m._State[n].eval() for n in m.VAR_NAMES])
+
+
+def advance(m, ticks, hook=None):
+    m.duration = ticks * m.dt_per_step * m.dt + 1e-9
+    for i in m.run():
+        if hook:
+            hook(i)
+
+
+def test_fenton_512_config1_vs_oracle(gpu_lib, orc):
+    """fenton.py __main__ (fenton.py:156-171): 512x512, diff 1.5, hole (256,256,30), S1; 1000 sub-steps"""
+    from fib_tf_amd.fenton import Fenton4v
+    m = Fenton4v(dict(BASE, height=512, width=512, diff=1.5))
+    m.add_hole_to_phase_field(256, 256, 30)
+    m.define()
+    ref = state(m)
+    advance(m, 100)
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 1000)
+    got = state(m)
+    err = np.abs(got.astype(np.float64) - ref).max()
+    assert err <= 1e-3, err                       # tolerance stated for 1000 sub-steps; measured ~4e-7
+
+
+@pytest.mark.parametrize('policy', ['fast', 'exact'])
+def test_fenton_512_plan_invariance(gpu_lib, policy, monkeypatch):
+    """the default plan (10 fused sub-steps, strip kernel), 2 x 5 fused, and 10 single-step launches give
+    bit-identical states at full size, pacing included"""
+    from fib_tf_amd.fenton import Fenton4v
+    out = {}
+    for variant in ('', '5,54,21,-3', '5,32,32,256', '1,64,4,256'):
+        if variant:
+            monkeypatch.setenv('FIBHIP_VARIANT', variant)
+        else:
+            monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+        m = Fenton4v(dict(BASE, height=512, width=512, diff=1.5, fast_math=policy == 'fast'))
+        m.add_hole_to_phase_field(256, 256, 30)
+        m.define()
+        m.add_pace_op('s2', 'luq', 1.0)
+        advance(m, 30, lambda i: m.fire_op('s2') if i == 21 else None)
+        out[variant] = state(m)
+    for k, v in out.items():
+        assert np.array_equal(v, out['']), 'plan %r changes the result' % k
+
+
+def test_fenton_mirror_symmetry_1024(gpu_lib):
+    """a problem that is mirror-symmetric about the horizontal mid-line stays so (to round-off: the
+    reference's diagonal sum is not associative under the mirror)"""
+    from fib_tf_amd.fenton import Fenton4v
+    H = 1024
+    m = Fenton4v(dict(BASE, height=H, width=640, diff=1.5))
+    m.add_hole_to_phase_field(300, (H - 1) / 2.0, 40)
+    assert np.array_equal(m.phase, m.phase[::-1])
+    m.define()
+    advance(m, 40)
+    s = state(m)
+    assert np.abs(s - s[:, ::-1]).max() < 2e-5
+    assert s[0].max() > 0.9                       # the S1 wave is really travelling
+
+
+def test_br_512_config2_vs_oracle(gpu_lib, orc):
+    """br.py __main__ (br.py:348-365): 512x512, diff 0.809, cheby=True, hole (150,200,40); 100 sub-steps"""
+    from fib_tf_amd.br import BeelerReuter
+    m = BeelerReuter(dict(BASE, height=512, width=512, diff=0.809))
+    m.add_hole_to_phase_field(150, 200, 40)
+    m.define()
+    ref = state(m)
+    advance(m, 20)
+    orc.br_run(ref, 0.1, 0.809, m.phase, m.chebyshev_table().astype(np.float32), False, 20)
+    got = state(m)
+    assert np.abs(got[0].astype(np.float64) - ref[0]).max() <= 2e-5 * 120.0
+    assert np.abs(got[2:].astype(np.float64) - ref[2:]).max() <= 2e-5
+
+
+def test_court_1024_config4_vs_oracle(gpu_lib, orc):
+    """court.py protocol scaled x2: 1024x1024, two holes, fast tick + 'slow' every 10th"""
+    from fib_tf_amd.court import Courtemanche
+    m = Courtemanche(dict(BASE, height=1024, width=1024, diff=0.809))
+    m.add_hole_to_phase_field(512, 512, 60)
+    m.add_hole_to_phase_field(512, 512, 500, neg=True)
+    m.define()
+    ref = state(m)
+    advance(m, 21, lambda i: m.fire_op('slow') if i % 10 == 0 else None)
+    orc.court_run(ref, 0.1, 0.809, m.phase, True, 0, 21)
+    got = state(m)
+    assert np.abs(got[0].astype(np.float64) - ref[0]).max() <= 2e-5 * 150.0
+    for i in range(1, 21):
+        sc = max(float(np.abs(ref[i]).max()), 1e-3)
+        assert np.abs(got[i].astype(np.float64) - ref[i]).max() <= 2e-5 * sc, m.VAR_NAMES[i]
