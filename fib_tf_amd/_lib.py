@@ -17,7 +17,10 @@ HDR = os.path.join(ROOT, 'include', 'fibhip.h')
 FENTON4V, BR, COURT = 0, 1, 2
 CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED = 1, 2, 4, 8, 16, 32
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
+# -ffp-contract=off: FMAs appear only where the source writes them (policy hook P::mad).
+# -fno-slp-vectorize: SLP packs pairs of f32 ops into v_pk_* instructions, which issue at half rate on
+#   gfx950 (tools/ubench/valu.hip) and need v_mov shuffles: 11 % slower on the Fenton kernel.
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared', '-std=c++17',
                '-Wall', '-Wno-unused-value', '-Wno-unused-result']
 
 

@@ -309,7 +309,8 @@ static int build_plan(fibhip_ctx *h)
                 const bool taller = tiles10 > 256 && t28 <= 256;
                 prefK = 10; want[0] = 44; want[1] = taller ? 28 : 25; want[2] = -3;
             } else {
-                prefK = 5; want[0] = 54; want[1] = 21; want[2] = (tiles5 <= 2048) ? -3 : -4;
+                (void)tiles5;
+                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -4;      // measured best at 1024^2 .. 4096^2
             }
             nwant = 1;
         }
