@@ -350,6 +350,9 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
         }
     }
     FIB_STAMP(1);
+    // all prologue loads are consumed by the first sub-step anyway: drain them once here, so that the
+    // compiler does not carry per-use `s_waitcnt vmcnt(n)` into every iteration of the step loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0) only
     __syncthreads();
     FIB_STAMP(2);
 
