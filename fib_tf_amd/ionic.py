@@ -101,16 +101,15 @@ class IonicModel:
         Must be called before define()."""
         if self.defined:
             raise AssertionError('add_hole_to_phase_field should be called before calling define')
-        if self.phase is None:
-            self.phase = np.ones([self.height, self.width], dtype=np.float32)
-        xx, yy = np.meshgrid(np.arange(self.width), np.arange(self.height))
-        dist = np.hypot(xx - x, yy - y)
-        if neg:
-            self.phase *= np.array(0.5 * (np.tanh(0.1 * (radius - dist)) + 1.0), dtype=np.float32)
-        else:
-            self.phase *= np.array(0.5 * (np.tanh(dist - radius) + 1.0), dtype=np.float32)
+        cols = np.arange(self.width)[np.newaxis, :] - x         # broadcasting instead of a meshgrid: same
+        rows = np.arange(self.height)[:, np.newaxis] - y        # float64 values, bit for bit
+        dist = np.hypot(cols, rows)
+        # smooth indicator of the kept region: outside the disc, or (neg) inside it with a 10x softer edge
+        arg = 0.1 * (radius - dist) if neg else dist - radius
+        mask = np.array(0.5 * (np.tanh(arg) + 1.0), dtype=np.float32)
+        base = np.ones([self.height, self.width], dtype=np.float32) if self.phase is None else self.phase
         # floor at 1e-5: phase_field divides by 4ϕ (ionic.py:104-105)
-        self.phase = np.maximum(self.phase, 1e-5)
+        self.phase = np.maximum(base * mask, 1e-5)
 
     # ---- pacing ----------------------------------------------------------------------------------
     def pace_rect(self, loc):
@@ -162,27 +161,14 @@ class IonicModel:
             raise AssertionError('run should be called after calling define')
         then = time.time()
         st = self._stepper
-        v0 = self.min_v
-        last_spike = 0
         self.samples = int(self.duration / (self.dt_per_step * self.dt))
+        every = int(self.dt_per_plot / self.dt_per_step) if im else 0
+        watch = {'v0': self.min_v, 'last_spike': 0}
         for i in range(self.samples):
             st.step(1)                           # == sess.run(self.ode_op(i)), ionic.py:203
             yield i
-            # a frame every dt_per_plot sub-steps, ionic.py:206-224
-            if im and i % int(self.dt_per_plot / self.dt_per_step) == 0:
-                image = self.image()
-                if self.phase is not None:
-                    image *= self.phase
-                im.imshow(image)
-                v1 = image[20, self.width // 2]
-                if v1 >= 0.5 and v0 < 0.5:
-                    cl = (i - last_spike) * self.dt_per_step * self.dt
-                    if self.cl_observer is None:
-                        print('wavefront reaches the middle top point at %d, cycle length is %d' % (i, cl))
-                    else:
-                        self.cl_observer(i, cl)
-                    last_spike = i
-                v0 = v1
+            if every and i % every == 0:         # a frame every dt_per_plot sub-steps, ionic.py:206
+                self._paint(im, i, watch)
         if keep_state:                           # ionic.py:226-229
             self.state = {}
             for s in self._State:
@@ -200,6 +186,22 @@ class IonicModel:
         print('elapsed: %f sec' % elapsed)
         if block and im:
             im.wait()
+
+    def _paint(self, im, i, watch):
+        """one frame + the cycle-length detector at pixel [20, width//2] (ionic.py:207-224)"""
+        image = self.image()
+        if self.phase is not None:
+            image *= self.phase
+        im.imshow(image)
+        v1 = image[20, self.width // 2]
+        if v1 >= 0.5 and watch['v0'] < 0.5:      # upstroke through 0.5 = a wavefront passes
+            cl = (i - watch['last_spike']) * self.dt_per_step * self.dt
+            if self.cl_observer is None:
+                print('wavefront reaches the middle top point at %d, cycle length is %d' % (i, cl))
+            else:
+                self.cl_observer(i, cl)
+            watch['last_spike'] = i
+        watch['v0'] = v1
 
     def millisecond_to_step(self, t):
         """milliseconds -> tick index returned by run(), ionic.py:247-252"""
