@@ -76,9 +76,25 @@ def cpu_baseline(args, seconds=12.0):
     run(slab, n)
     dt = time.perf_counter() - t0
     cells = slab.shape[1] * slab.shape[2]
-    return {'value': round(cells * n / dt / 1e6, 2), 'unit': 'Mcell-steps/s', 'cores': oracle.num_threads(),
+    threads = oracle.num_threads()
+    # one-thread figure (a scalar port of the reference), about 3 s
+    oracle.set_threads(1)
+    n1 = int(max(10, min(3.0 / (per * threads * 0.6), 20000)))
+    t0 = time.perf_counter()
+    run(slab, n1)
+    dt1 = time.perf_counter() - t0
+    oracle.set_threads(threads)
+    model_name = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            model_name = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
+    except OSError:
+        pass
+    return {'value': round(cells * n / dt / 1e6, 2), 'unit': 'Mcell-steps/s', 'cores': threads,
             'kind': 'port', 'sample': '%d sub-steps of the same %dx%d %s workload (%.1f s), oracle/fib_oracle.c '
-            'with OpenMP' % (n, slab.shape[1], slab.shape[2], args.model, dt)}
+            'with OpenMP' % (n, slab.shape[1], slab.shape[2], args.model, dt),
+            'value_1thread': round(cells * n1 / dt1 / 1e6, 2), 'cpu_model': model_name,
+            'host_cpu_count': os.cpu_count(), 'omp_num_threads': os.environ.get('OMP_NUM_THREADS', 'unset')}
 
 
 def make_model_host(args):
