@@ -580,3 +580,20 @@ def test_c_abi_argument_checks(gpu_lib):
     with pytest.raises(_lib.FibhipError, match='out of range'):
         c.probe(0, 8, 0)
     c.close()
+
+
+def test_timeline_and_save_graph_keys(gpu_lib, tmp_path):
+    """config['timeline'] / ['timeline_name'] / ['save_graph'] of the reference (ionic.py:190-191,231-241):
+    timeline writes a Chrome-trace JSON for one extra tick; save_graph is accepted and ignored"""
+    import json
+    from fib_tf_amd.fenton import Fenton4v
+    name = str(tmp_path / 'timeline_4v.json')
+    m = Fenton4v(cfg(64, 64, 1.5, 'fast', duration=5, timeline=True, timeline_name=name, save_graph=True))
+    m.define()
+    before = None
+    for i in m.run():
+        before = i
+    assert before == 4
+    tr = json.load(open(name))
+    ev = tr['traceEvents'][0]
+    assert ev['ph'] == 'X' and ev['dur'] > 0 and 'sub-steps fused' in ev['name']
