@@ -204,8 +204,8 @@ def bench_single(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1000, help='ticks timed (1 tick = dt_per_step sub-steps)')
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=5000, help='ticks timed (1 tick = dt_per_step sub-steps)')
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--model', default='fenton', choices=['fenton', 'br', 'court'])
     ap.add_argument('--size', type=int, default=0, help='grid width (and height at N=1); default 512 (1024 court)')
     ap.add_argument('--rows-per-gpu', type=int, default=512)
