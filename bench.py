@@ -209,6 +209,9 @@ def main():
     ap.add_argument('--model', default='fenton', choices=['fenton', 'br', 'court'])
     ap.add_argument('--size', type=int, default=0, help='grid width (and height at N=1); default 512 (1024 court)')
     ap.add_argument('--rows-per-gpu', type=int, default=512)
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N>1: weak = rows-per-gpu rows on every GPU (default); strong = the fixed size x size grid '
+                         'split over the N GPUs (north_star\'s "512x512 at 1/2/4/8")')
     ap.add_argument('--exact', action='store_true', help="config['fast_math']=False: one rounding per reference op")
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')

@@ -315,7 +315,8 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
     import torch
     import torch.distributed as dist
     rank, world, local = init_from_env()
-    H = args.rows_per_gpu * world
+    strong = getattr(args, 'scaling', 'weak') == 'strong'
+    H = args.size if strong else args.rows_per_gpu * world
     m, (loc, amp, s2_ms) = make_model(args, height=H, device=local)
     m.define()
     m.add_pace_op('s2', loc, amp)
@@ -364,10 +365,10 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                 args.model, H, m.width, world),
             'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(wall * 1000.0 / args.steps, 6), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s %dx%d grid = %d rows x %d cols per GPU (weak scaling of BASELINE configs[1] by '
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d grid = %d rows x %d cols per GPU (%s scaling of BASELINE configs[1] by '
                                    'rows), dt=0.1 ms, phase-field hole, S1 + S2; 1 step = 1 tick = %d sub-steps'
-                                   % (args.model, H, m.width, args.rows_per_gpu, m.width, spt),
+                                   % (args.model, H, m.width, H // world, m.width, 'strong' if strong else 'weak', spt),
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one RCCL send/recv pair per '
                                       'neighbour every %d ticks, %d arrays in one contiguous message, interior '
