@@ -182,6 +182,9 @@ class ShardedStepper:
         return self.eng.var_view(idx, var)
 
     def _tick(self):
+        if not self.eng.halo_due():                         # mid-cycle tick: one C call, no torch involved
+            self.eng.step(1)
+            return
         with self.eng.stream_ctx():
             self._tick_on_stream()
 
@@ -203,10 +206,6 @@ class ShardedStepper:
     def _tick_on_stream(self):
         torch, dist, e, g = self.torch, self.dist, self.eng, self.g
         e.step_edges()
-        if not e.halo_due():                                # mid-cycle tick: nothing to exchange
-            e.step_interior()
-            e.step_commit()
-            return
         t0 = time.perf_counter()
         b = self.gt + self.rows
         idxs = {e.next_buf(v)[0] for v in range(self.halo_n)}

@@ -101,6 +101,12 @@ class OracleEngine:
     def step_interior(self):
         pass
 
+    def step(self, n=1):
+        for _ in range(n):
+            self.step_edges()
+            self.step_interior()
+            self.step_commit()
+
     def step_commit(self):
         self.cur ^= 1
         self.cpos = (self.cpos + 1) % self.cycle
