@@ -93,6 +93,11 @@ struct Exact {
     }
     template <class T>
     static FIB_DEV T tanhv(const T &a) { return vmap(a, [](float x) { return tanhf(x); }); }
+    // 1 + tanh(a) and 0.5*(1 + tanh(a)) - s, as the reference writes them (fenton.py:83,90)
+    template <class T>
+    static FIB_DEV T one_plus_tanh(const T &a) { return 1.0f + tanhv(a); }
+    template <class T>
+    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return (1.0f + tanhv(a)) * 0.5f + (-s); }
     static FIB_DEV float div(float a, float b) { return a / b; }
     static FIB_DEV float rcp(float a) { return 1.0f / a; }
     static FIB_DEV float exp(float a) { return expf(a); }
@@ -118,6 +123,18 @@ struct Fast {
         const T q = vmap(d, [](float x) { return __builtin_amdgcn_rcpf(x); });
         return 1.0f - 2.0f * q;
     }
+    // q = 1/(exp(2a)+1):  1 + tanh = 2 - 2q,  0.5*(1 + tanh) - s = (1 - q) - s   (one instruction fewer each)
+    template <class T>
+    static FIB_DEV T sigm_q(const T &a)
+    {
+        const T t = a * (2.0f * 1.44269504088896340736f);
+        const T e = vmap(t, [](float x) { return __builtin_amdgcn_exp2f(x); });
+        return vmap(e + 1.0f, [](float x) { return __builtin_amdgcn_rcpf(x); });
+    }
+    template <class T>
+    static FIB_DEV T one_plus_tanh(const T &a) { return vfma(sigm_q(a), -2.0f, 2.0f); }
+    template <class T>
+    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return (1.0f - sigm_q(a)) - s; }
     static FIB_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
     static FIB_DEV float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
     static FIB_DEV float exp(float a) { return __expf(a); }
