@@ -60,6 +60,10 @@ template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, float b, float c)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b, c); return o; }
 template <int R, class F> FIB_DEV vf<R> vmap(const vf<R> &a, F f)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r]); return o; }
+template <int R, class F> FIB_DEV vf<R> vzip(const vf<R> &a, const vf<R> &b, F f)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r], b.v[r]); return o; }
+template <int R, class F> FIB_DEV vf<R> vzip(float a, const vf<R> &b, F f)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a, b.v[r]); return o; }
 template <class T> struct bcast;
 template <> struct bcast<float> { static FIB_DEV float of(float x) { return x; } };
 template <int R> struct bcast<vf<R>> { static FIB_DEV vf<R> of(float x) { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = x; return o; } };
@@ -73,6 +77,7 @@ FIB_DEV bool vgt(float a, float b) { return a > b; }
 FIB_DEV float vsel(bool m, float a, float b) { return m ? a : b; }
 FIB_DEV float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <class F> FIB_DEV float vmap(float a, F f) { return f(a); }
+template <class F> FIB_DEV float vzip(float a, float b, F f) { return f(a, b); }
 
 // Division by a value whose correctly rounded reciprocal rc = RN(1/c) is known (a compile-time
 // constant, or the per-cell 1/(4ϕ) prepared once): q = RN(a*rc); r = a - q*c (exact, one FMA);
@@ -98,11 +103,12 @@ struct Exact {
     static FIB_DEV T one_plus_tanh(const T &a) { return 1.0f + tanhv(a); }
     template <class T>
     static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return (1.0f + tanhv(a)) * 0.5f + (-s); }
-    static FIB_DEV float div(float a, float b) { return a / b; }
-    static FIB_DEV float rcp(float a) { return 1.0f / a; }
-    static FIB_DEV float exp(float a) { return expf(a); }
-    static FIB_DEV float expm1(float a) { return expm1f(a); }
-    static FIB_DEV float log(float a) { return logf(a); }
+    template <class A, class T>
+    static FIB_DEV T div(const A &a, const T &b) { return vzip(a, b, [](float x, float y) { return x / y; }); }
+    template <class T> static FIB_DEV T rcp(const T &a) { return vmap(a, [](float x) { return 1.0f / x; }); }
+    template <class T> static FIB_DEV T exp(const T &a) { return vmap(a, [](float x) { return expf(x); }); }
+    template <class T> static FIB_DEV T expm1(const T &a) { return vmap(a, [](float x) { return expm1f(x); }); }
+    template <class T> static FIB_DEV T log(const T &a) { return vmap(a, [](float x) { return logf(x); }); }
     static FIB_DEV float tanh(float a) { return tanhf(a); }   // == tanhv<float>
     static FIB_DEV float sqrt(float a) { return sqrtf(a); }
 };
@@ -135,19 +141,22 @@ struct Fast {
     static FIB_DEV T one_plus_tanh(const T &a) { return vfma(sigm_q(a), -2.0f, 2.0f); }
     template <class T>
     static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return (1.0f - sigm_q(a)) - s; }
-    static FIB_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-    static FIB_DEV float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
-    static FIB_DEV float exp(float a) { return __expf(a); }
+    template <class T> static FIB_DEV T rcp(const T &a) { return vmap(a, [](float x) { return __builtin_amdgcn_rcpf(x); }); }
+    template <class A, class T>
+    static FIB_DEV T div(const A &a, const T &b) { return a * rcp(b); }
+    template <class T> static FIB_DEV T exp(const T &a) { return vmap(a, [](float x) { return __expf(x); }); }
     // expm1 for the Rush-Larsen factor: argument is -dt/tau.  exp(x)-1 keeps an absolute error of
     // ~1 ulp(1) = 6e-8, which is below the float32 resolution of the gate value it multiplies into.
-    static FIB_DEV float expm1(float a) { return __expf(a) - 1.0f; }
-    static FIB_DEV float log(float a) { return __logf(a); }
+    template <class T> static FIB_DEV T expm1(const T &a) { return exp(a) - 1.0f; }
+    template <class T> static FIB_DEV T log(const T &a) { return vmap(a, [](float x) { return __logf(x); }); }
     static FIB_DEV float tanh(float a) { return tanhv<float>(a); }
     static FIB_DEV float sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 };
 
 static FIB_DEV float sgnf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 static FIB_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+template <int R> static FIB_DEV vf<R> clipf(const vf<R> &x, float lo, float hi)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = fminf(fmaxf(x.v[r], lo), hi); return o; }
 
 // (1 + sign(x)) * 0.5 and (1 - sign(x)) * 0.5 (fenton.py:73-79): the three values {0, 0.5, 1}, produced as
 // clamp(0.5 +- x * 2^27, 0, 1) — one instruction, no compare (compares write SGPRs and issue at ~60 %
@@ -158,8 +167,8 @@ template <class T> static FIB_DEV T heav(const T &x) { return vfma_sat(x, 134217
 template <class T> static FIB_DEV T heav_not(const T &x) { return vfma_sat(x, -134217728.0f, 0.5f); }
 
 // rush_larsen, ionic.py:115-123.  mdt = float(-dt)
-template <class P>
-static FIB_DEV float rush_larsen(float g, float ginf, float tau, float mdt)
+template <class P, class T>
+static FIB_DEV T rush_larsen(const T &g, const T &ginf, const T &tau, float mdt)
 {
     return clipf(g + (g - ginf) * P::expm1(P::div(mdt, tau)), 0.00001f, 0.99999f);
 }
@@ -231,7 +240,6 @@ struct Fenton {
 struct BeelerReuter {
     static constexpr int NVAR = 8;                // V C M H J D F XI, br.py:87-94
     static constexpr int DEFAULT_STEPS = 5;       // br.py:98-107
-    static constexpr bool HAS_VEC = false;
     template <class C> static FIB_DEV const C &pinned(const C &k) { return k; }
     enum { MODE_DIRECT = 0, MODE_CHEBY = 1 };
     struct Consts {
@@ -245,34 +253,58 @@ struct BeelerReuter {
 
     // calc_alpha_bata_tf, br.py:255-264, with the row of ab_coef (br.py:49-62) as template constants.
     // The table is float32; the d/f rows are pre-multiplied by 2 in double first.
-    template <class P>
-    static FIB_DEV float ab(float v, float c0, float c1, float c2, float c3, float c4, float c5, float c6)
+    template <class P, class T>
+    static FIB_DEV T ab(const T &v, float c0, float c1, float c2, float c3, float c4, float c5, float c6)
     {
-        const float e1 = P::exp(c1 * (v + c2));
-        const float den = P::exp(c5 * (v + c2)) + c6;
+        const T e1 = P::exp(c1 * (v + c2));
+        const T den = P::exp(c5 * (v + c2)) + c6;
         if (c3 == 0.0f) return P::div(c0 * e1, den);
         return P::div(c0 * e1 + c3 * (v + c4), den);
     }
-    template <class P>
-    static FIB_DEV void inf_tau(float a, float b, float &inf, float &tau)
+    template <class P, class T>
+    static FIB_DEV void inf_tau(const T &a, const T &b, T &inf, T &tau)
     {   // calc_inf_tau, br.py:266-273
         inf = P::div(a, a + b);
         tau = P::div(1.0f, a + b);
     }
     // expand_chebyshev device part, br.py:329-331:  r = d0; r += d_i * S_i  (i ascending)
     // (P unused: the degree-8 sums keep the reference's rounding points under both policies — they
-    // amplify an ulp by ~1e2, and Beeler-Reuter is not instruction-bound at one sub-step per launch)
-    template <class P>
-    static FIB_DEV float cheb(const float *d, const float (&S)[9])
+    // amplify an ulp by ~1e2)
+    template <class P, class T>
+    static FIB_DEV T cheb(const float *d, const T (&S)[9])
     {
-        float r = d[0];
+        T r = d[0] + d[1] * S[1];
 #pragma unroll
-        for (int i = 1; i <= 8; ++i) r = r + d[i] * S[i];
+        for (int i = 2; i <= 8; ++i) r = r + d[i] * S[i];
         return r;
     }
 
     template <class P, int MODE>
     static FIB_DEV void step(float (&s)[NVAR], float V0, float lap, const Consts &k, int sub)
+    {
+        body<P, MODE, float>(s, V0, lap, k, sub);
+    }
+    // the R cells of a lane at once (strip kernel), operation-major like Fenton::stepN
+    static constexpr bool HAS_VEC = true;
+    template <class P, int MODE, int R>
+    static FIB_DEV void stepN(float (&s)[R][NVAR], const float (&V0)[R], const float (&lap)[R], const Consts &k, int sub)
+    {
+        vf<R> t[NVAR], v0, l;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int v = 0; v < NVAR; ++v) t[v].v[r] = s[r][v];
+            v0.v[r] = V0[r];
+            l.v[r] = lap[r];
+        }
+        body<P, MODE, vf<R>>(t, v0, l, k, sub);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < NVAR; ++v) s[r][v] = t[v].v[r];
+    }
+    template <class P, int MODE, class T>
+    static FIB_DEV void body(T (&s)[NVAR], const T &V0, const T &lap, const Consts &k, int sub)
     {
 #include "br_step.inc"
     }
