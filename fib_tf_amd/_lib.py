@@ -14,7 +14,7 @@ SO = os.path.join(HERE, 'libfibhip.so')
 SRC = os.path.join(HERE, 'csrc', 'fibhip.hip')
 HDR = os.path.join(ROOT, 'include', 'fibhip.h')
 
-FENTON4V, BR, COURT = 0, 1, 2
+FENTON4V, BR, COURT, COURT_US = 0, 1, 2, 3
 CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED = 1, 2, 4, 8, 16, 32
 
 # -ffp-contract=off: FMAs appear only where the source writes them (policy hook P::mad).
@@ -67,6 +67,7 @@ SYMBOLS = {
     'fibhip_halo_due': ([_h], C.c_int),
     'fibhip_unit_op': ([C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_double, C.c_int, _fp],
                        C.c_int),
+    'fibhip_court_inter': ([C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -127,6 +128,21 @@ def unit_op(op, a, b=None, c=None, phi=None, dt=0.0, fast=False, device=0):
     check(lib().fibhip_unit_op(device, op, H, W, _ptr(a), _ptr(b), _ptr(c), _ptr(phi), float(dt), int(fast),
                                _ptr(out)))
     return out
+
+
+COURT_INTER_KEYS = ('d_infinity', 'tau_d', 'f_infinity', 'tau_f', 'tau_w', 'w_infinity', 'm_inf', 'tau_m', 'h_inf',
+                    'tau_h', 'j_inf', 'tau_j', 'tau_oa', 'oa_infinity', 'tau_oi', 'oi_infinity', 'tau_ua',
+                    'ua_infinity', 'tau_ui', 'ui_infinity', 'tau_xr', 'xr_infinity', 'tau_xs', 'xs_infinity', 'g_Kur',
+                    'f_NaK', 'i_NaCaa', 'i_NaCab', 'i_K1a', 'i_Kra', 'us_infinity', 'tau_us')
+
+
+def court_inter(V, fast=False, device=0):
+    """the voltage-only intermediates of the Courtemanche model for an array (or scalar) of voltages:
+    dict key -> float32 array shaped like V (court.py:273-429, court_ultra.py:445-450)"""
+    v = _f32(V)
+    out = np.empty((len(COURT_INTER_KEYS), v.size), np.float32)
+    check(lib().fibhip_court_inter(device, v.size, _ptr(v.reshape(-1)), int(fast), _ptr(out)))
+    return {k: out[i].reshape(v.shape) for i, k in enumerate(COURT_INTER_KEYS)}
 
 
 class Stepper:

@@ -45,10 +45,12 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 // kernel variants
 // ------------------------------------------------------------------------------------------
+constexpr int FIB_MAXVAR = 22;   // CourtemancheUS
+
 struct LaunchCtx {
     Geo g;
-    const float *in[21];
-    float *out[21];
+    const float *in[FIB_MAXVAR];
+    float *out[FIB_MAXVAR];
     PhaseTab ph;
     const void *consts;
     int sub0;
@@ -180,6 +182,8 @@ static const Variant g_variants[] = {
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 4, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
+    // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
+    V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
 };
 static const int g_nvariants = (int)(sizeof g_variants / sizeof g_variants[0]);
 
@@ -205,8 +209,8 @@ struct fibhip_ctx {
     float *phase3;          // dpy | dpx | q4 | r4, each `cells` floats
     float *phi_dev;
     bool has_phase;
-    int cur[21];            // which slab holds variable v
-    int nxt[21];            // where the tick in flight writes it (valid between edges and commit)
+    int cur[FIB_MAXVAR];            // which slab holds variable v
+    int nxt[FIB_MAXVAR];            // where the tick in flight writes it (valid between edges and commit)
     bool has_consts;
     Fenton::Consts kf;
     BeelerReuter::Consts kb;
@@ -238,6 +242,7 @@ extern "C" int fibhip_nvar(int model)
     case FIBHIP_FENTON4V: return Fenton::NVAR;
     case FIBHIP_BR: return BeelerReuter::NVAR;
     case FIBHIP_COURT: return Courtemanche::NVAR;
+    case FIBHIP_COURT_US: return CourtemancheUS::NVAR;
     default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
     }
 }
@@ -248,6 +253,7 @@ extern "C" int fibhip_default_steps_per_tick(int model)
     case FIBHIP_FENTON4V: return Fenton::DEFAULT_STEPS;
     case FIBHIP_BR: return BeelerReuter::DEFAULT_STEPS;
     case FIBHIP_COURT: return Courtemanche::DEFAULT_STEPS;
+    case FIBHIP_COURT_US: return CourtemancheUS::DEFAULT_STEPS;
     default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
     }
 }
@@ -390,6 +396,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     if (desc->model == FIBHIP_BR && (desc->flags & FIBHIP_CHEBY)) h->mode = BeelerReuter::MODE_CHEBY;
     if (desc->model == FIBHIP_COURT)
         h->mode = (desc->flags & FIBHIP_ALLVARS) ? Courtemanche::MODE_ALL : Courtemanche::MODE_FAST;
+    if (desc->model == FIBHIP_COURT_US) h->mode = CourtemancheUS::MODE_ALL;
     const int ming = (desc->ghost_top && desc->ghost_bottom)
                          ? (desc->ghost_top < desc->ghost_bottom ? desc->ghost_top : desc->ghost_bottom)
                          : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
@@ -409,7 +416,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->kb.skip = (desc->flags & FIBHIP_SKIP) ? 1 : 0;
     memset(h->kb.cheb, 0, sizeof h->kb.cheb);
     {
-        const bool all = (desc->flags & FIBHIP_ALLVARS) != 0;
+        const bool all = (desc->flags & FIBHIP_ALLVARS) != 0 || desc->model == FIBHIP_COURT_US;
         const double dts = all ? dt : dt * 10;                     // court.py:118-122
         const double chronic = (desc->flags & FIBHIP_CHRONIC) ? 1.0 : 0.0;
         h->kc.dtf = (float)dt;
@@ -457,7 +464,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     HIPCHK(hipMalloc((void **)&h->phi_dev, h->cells * sizeof(float)));
     HIPCHK(hipHostMalloc((void **)&h->probe_host, 64, hipHostMallocDefault));
     h->has_phase = false;
-    for (int v = 0; v < 21; ++v) h->cur[v] = h->nxt[v] = 0;
+    for (int v = 0; v < FIB_MAXVAR; ++v) h->cur[v] = h->nxt[v] = 0;
     h->phase_of_tick = 0;
     h->launches = 0;
     return build_plan(h);
@@ -661,13 +668,13 @@ extern "C" int fibhip_step_edges(fibhip_t h)
     NEED(h);
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step_edges: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
-    int cur[21];
+    int cur[FIB_MAXVAR];
     memcpy(cur, h->cur, sizeof cur);
     int sub = 0;
     for (size_t l = 0; l < h->plan.size(); ++l) {
         const PlanItem &it = h->plan[l];
         LaunchCtx c;
-        int nxt[21];
+        int nxt[FIB_MAXVAR];
         fill_ptrs(h, c, it.K, cur, nxt);
         c.sub0 = sub;
         int r0, r1;
@@ -708,19 +715,19 @@ extern "C" int fibhip_step_interior(fibhip_t h)
         return 0;
     }
     // recompute the last launch's geometry (same arithmetic as step_edges)
-    int cur[21];
+    int cur[FIB_MAXVAR];
     memcpy(cur, h->cur, sizeof cur);
     int sub = 0;
     for (size_t l = 0; l + 1 < h->plan.size(); ++l) {
         LaunchCtx tmp;
-        int nxt[21];
+        int nxt[FIB_MAXVAR];
         fill_ptrs(h, tmp, h->plan[l].K, cur, nxt);
         memcpy(cur, nxt, sizeof cur);
         sub += h->plan[l].K;
     }
     const PlanItem &it = h->plan.back();
     LaunchCtx c;
-    int nxt[21];
+    int nxt[FIB_MAXVAR];
     fill_ptrs(h, c, it.K, cur, nxt);
     c.sub0 = sub;
     int r0, r1;
@@ -869,6 +876,33 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
             hipLaunchKernelGGL(unit_op_kernel<Exact>, dim3(256), dim3(256), 0, 0, op, H, W, da, db, dc, phi ? dph3 : nullptr, mdt, dout);
         if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, B, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(FIBHIP_EHIP, "unit_op: kernel or D2H failed");
+            break;
+        }
+    } while (0);
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int fibhip_court_inter(int device, int n, const float *V, int fast, float *out)
+{
+    if (!V || !out || n <= 0) return fail(FIBHIP_EINVAL, "court_inter: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    float *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)(1 + COURT_NINTER) * n * sizeof(float)));
+    int rc = 0;
+    do {
+        if (hipMemcpy(d, V, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "court_inter: H2D failed"); break; }
+        const int blocks = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+        if (fast)
+            hipLaunchKernelGGL(court_inter_kernel<Fast>, dim3(blocks), dim3(256), 0, 0, n, d, d + n);
+        else
+            hipLaunchKernelGGL(court_inter_kernel<Exact>, dim3(blocks), dim3(256), 0, 0, n, d, d + n);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpy(out, d + n, (size_t)COURT_NINTER * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(FIBHIP_EHIP, "court_inter: kernel or D2H failed");
             break;
         }
     } while (0);

@@ -550,4 +550,22 @@ __global__ void pace_kernel(Geo g, float *pot, int r0, int r1, int c0, int c1, f
     }
 }
 
+// calc_inter(V, mod) as a stand-alone op (court.py:273-429, court_ultra.py:445-450): the 32 voltage-only
+// intermediates of n voltages, row k of `out` = k-th key in the reference dict's insertion order.
+constexpr int COURT_NINTER = 32;
+template <class P>
+__global__ void court_inter_kernel(int n, const float *__restrict__ V, float *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        CourtemancheUS::Inter q;
+        CourtemancheUS::calc_inter<P>(V[i], q);
+        const float v[COURT_NINTER] = {q.d_inf, q.tau_d, q.f_inf, q.tau_f, q.tau_w, q.w_inf, q.m_inf, q.tau_m,
+                                       q.h_inf, q.tau_h, q.j_inf, q.tau_j, q.tau_oa, q.oa_inf, q.tau_oi, q.oi_inf,
+                                       q.tau_ua, q.ua_inf, q.tau_ui, q.ui_inf, q.tau_xr, q.xr_inf, q.tau_xs, q.xs_inf,
+                                       q.g_Kur, q.f_NaK, q.i_NaCaa, q.i_NaCab, q.i_K1a, q.i_Kra, q.us_inf, q.tau_us};
+#pragma unroll
+        for (int k = 0; k < COURT_NINTER; ++k) out[(size_t)k * n + i] = v[k];
+    }
+}
+
 }  // namespace fib

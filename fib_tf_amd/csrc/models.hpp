@@ -313,35 +313,41 @@ struct BeelerReuter {
 // =====================================================================================
 // Courtemanche  (court.py:124-429)
 // =====================================================================================
-struct Courtemanche {
-    static constexpr int NVAR = 21;
+struct CourtConsts {
+    float dtf, dts;        // float(δt) for the fast / slow sets (court.py:118-122)
+    float mdt_f, mdt_s;    // float(-δt)
+    float ddt;             // float(diff * dt)
+    float em1_fCa, em1_u;  // expm1(float(-δt/tau)) for the two constant-tau gates (:189,:243)
+    float chronic;         // 1.0 / 0.0
+    // Python-side products that depend on `chronic` (court.py:193,194,218)
+    float c_to, c_Kur, c_CaL;
+};
+
+// US = court_ultra.py's optional 22nd gate `_us_` (ultra-slow sodium inactivation,
+// court_ultra.py:81-82,198-199,221-222,445-450); only meaningful with MODE_ALL
+template <bool US>
+struct CourtT {
+    static constexpr int NVAR = 21 + (US ? 1 : 0);
     static constexpr int DEFAULT_STEPS = 1;       // court.py:92
     static constexpr bool HAS_VEC = false;
     template <class C> static FIB_DEV const C &pinned(const C &k) { return k; }
     enum { iV, iNa_i, i_m, i_h, i_j, iK_i, i_oa, i_oi, i_ua, i_ui, i_xr, i_xs, iCa_i, i_d, i_f, i_f_Ca,
-           iCa_rel, i_u, i_v, i_w, iCa_up };
+           iCa_rel, i_u, i_v, i_w, iCa_up, i_us };
     // MODE_FAST: the 4 fast_states (court.py:42,94-102); MODE_SLOW: the other 17 (court.py:103);
     // MODE_ALL: all 21 in one evaluation (court_ultra.py:107-111)
     enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_ALL = 2 };
-    static constexpr unsigned FAST_MASK = 0xFu, ALL_MASK = (1u << 21) - 1u;
+    static constexpr unsigned FAST_MASK = 0xFu, ALL_MASK = (1u << NVAR) - 1u;
     static constexpr unsigned mask(int mode)
     {
         return mode == MODE_FAST ? FAST_MASK : (mode == MODE_SLOW ? (ALL_MASK & ~FAST_MASK) : ALL_MASK);
     }
-    struct Consts {
-        float dtf, dts;        // float(δt) for the fast / slow sets (court.py:118-122)
-        float mdt_f, mdt_s;    // float(-δt)
-        float ddt;             // float(diff * dt)
-        float em1_fCa, em1_u;  // expm1(float(-δt/tau)) for the two constant-tau gates (:189,:243)
-        float chronic;         // 1.0 / 0.0
-        // Python-side products that depend on `chronic` (court.py:193,194,218)
-        float c_to, c_Kur, c_CaL;
-    };
+    using Consts = CourtConsts;
 
     struct Inter {
         float d_inf, tau_d, f_inf, tau_f, tau_w, w_inf, m_inf, tau_m, h_inf, tau_h, j_inf, tau_j;
         float tau_oa, oa_inf, tau_oi, oi_inf, tau_ua, ua_inf, tau_ui, ui_inf, tau_xr, xr_inf, tau_xs, xs_inf;
         float g_Kur, f_NaK, i_NaCaa, i_NaCab, i_K1a, i_Kra;
+        float us_inf, tau_us;
     };
 
     // calc_inter(V, tf), court.py:273-429.  Fully inlined; whatever a MODE does not use is dead code.
@@ -360,5 +366,7 @@ struct Courtemanche {
 #include "court_step.inc"
     }
 };
+using Courtemanche = CourtT<false>;
+using CourtemancheUS = CourtT<true>;
 
 }  // namespace fib

@@ -33,7 +33,11 @@ extern "C" {
 
 typedef struct fibhip_ctx *fibhip_t;
 
-enum fibhip_model { FIBHIP_FENTON4V = 0, FIBHIP_BR = 1, FIBHIP_COURT = 2 };
+enum fibhip_model {
+    FIBHIP_FENTON4V = 0, FIBHIP_BR = 1, FIBHIP_COURT = 2,
+    FIBHIP_COURT_US = 3   /* court_ultra.py with config['ultra_slow']: a 22nd array `_us_` (court_ultra.py:81-82,  */
+                          /* 198-199,221-222,445-450); always single-rate (implies FIBHIP_ALLVARS)                */
+};
 
 enum fibhip_flags {
     FIBHIP_CHEBY   = 1u << 0, /* BR: Chebyshev gates, config['cheby'] (br.py:132-135); needs set_consts   */
@@ -151,6 +155,14 @@ int fibhip_halo_due(fibhip_t h);
  *    3 = rush_larsen(a=g, b=g_inf, c=tau, dt)  ionic.py:115-123                                         */
 int fibhip_unit_op(int device, int op, int height, int width, const float *a, const float *b, const float *c,
                    const float *phi, double dt, int fast, float *out);
+
+/* Courtemanche.calc_inter(V, mod) (court.py:273-429; court_ultra.py:445-450 for the last two) on a HOST array
+ * of n voltages: out[k*n + i] = k-th intermediate of V[i], k in the insertion order of the reference's dict:
+ * d_infinity tau_d f_infinity tau_f tau_w w_infinity m_inf tau_m h_inf tau_h j_inf tau_j tau_oa oa_infinity
+ * tau_oi oi_infinity tau_ua ua_infinity tau_ui ui_infinity tau_xr xr_infinity tau_xs xs_infinity g_Kur f_NaK
+ * i_NaCaa i_NaCab i_K1a i_Kra us_infinity tau_us   (FIBHIP_COURT_NINTER = 32 rows)                        */
+#define FIBHIP_COURT_NINTER 32
+int fibhip_court_inter(int device, int n, const float *V, int fast, float *out);
 
 /* introspection for DESIGN/bench: sub-steps fused per launch and launches per tick                      */
 int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick);

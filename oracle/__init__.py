@@ -61,6 +61,8 @@ def lib():
             'orc_br_run': [i, i, d, d, _fp, _fp, i, _fp, _fp, i],
             'orc_court_run': [i, i, d, d, _fp, i, _fp, _fp, i, i, i],
             'orc_court_ultra_run': [i, i, d, d, _fp, i, _fp, _fp, i],
+            'orc_court_ultra_us_run': [i, i, d, d, _fp, i, _fp, _fp, i],
+            'orc_court_us_inter': [f, _fp, _fp],
         }
         for name, args in sig.items():
             fn = getattr(_lib, name)
@@ -183,6 +185,26 @@ def court_ultra_run(slab, dt, diff, phi, chronic, nticks):
     tmp = np.empty(23 * H * W, np.float32); phi = _phi(phi, H, W)
     lib().orc_court_ultra_run(H, W, dt, diff, _p(phi), int(chronic), _p(slab), _p(tmp), nticks)
     return slab
+
+
+def court_ultra_us_run(slab, dt, diff, phi, chronic, nticks):
+    """court_ultra.py with ultra_slow=True: 22 arrays (`_us_` last), single rate"""
+    assert slab.dtype == np.float32 and slab.flags.c_contiguous and slab.shape[0] == 22
+    _, H, W = slab.shape
+    tmp = np.empty(24 * H * W, np.float32); phi = _phi(phi, H, W)
+    lib().orc_court_ultra_us_run(H, W, dt, diff, _p(phi), int(chronic), _p(slab), _p(tmp), nticks)
+    return slab
+
+
+def court_us_inter(V):
+    """(us_infinity, tau_us) of court_ultra.py:445-450 for an array of voltages"""
+    V = np.ascontiguousarray(V, np.float32)
+    a, b = np.empty_like(V), np.empty_like(V)
+    x, y = C.c_float(), C.c_float()
+    for k, v in enumerate(V.ravel()):
+        lib().orc_court_us_inter(C.c_float(v), C.byref(x), C.byref(y))
+        a.ravel()[k], b.ravel()[k] = x.value, y.value
+    return a, b
 
 
 def host_cores():

@@ -436,8 +436,20 @@ void orc_court_step(int H, int W, double dt, double diff, const float *phi, int 
 
 /* slow_mult = 10: court.py (δt = 10·dt for the slow set, court.py:118-122);
  * slow_mult = 1 : court_ultra.py (δt = dt for every variable, court_ultra.py:127-128)              */
+static void court_step_impl(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
+                            double slow_mult, const float *in, float *out, float *scratch,
+                            const float *us_in, float *us_out);
+
 void orc_court_step_rate(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
                          double slow_mult, const float *in, float *out, float *scratch)
+{
+    court_step_impl(H, W, dt, diff, phi, chronic_flag, slow_mult, in, out, scratch, NULL, NULL);
+}
+
+/* us_in/us_out: court_ultra.py's optional 22nd array `_us_` (court_ultra.py:198-199,221-222,445-450) */
+static void court_step_impl(int H, int W, double dt, double diff, const float *phi, int chronic_flag,
+                            double slow_mult, const float *in, float *out, float *scratch,
+                            const float *us_in, float *us_out)
 {
     const long n = (long)H * W;
     float *Va = scratch, *lap = scratch + n;
@@ -495,7 +507,14 @@ void orc_court_step_rate(int H, int W, double dt, double diff, const float *phi,
                       ((2.0f * i_NaK - (((((i_K1 + i_to) + i_Kur) + i_Kr) + i_Ks) + i_B_K)) / ViF) * dts;
         /* sodium, court.py:206-215 */
         const float E_Na = RTF * logf(F(Na_o) / s[cNa_i]);
-        const float i_Na = (((F(Cm * g_Na) * powf(s[c_m], 3.0f)) * s[c_h]) * s[c_j]) * (V - E_Na);
+        float i_Na = (((F(Cm * g_Na) * powf(s[c_m], 3.0f)) * s[c_h]) * s[c_j]) * (V - E_Na);
+        if (us_in) {
+            /* alpha_us, beta_us, us_infinity, tau_us: court_ultra.py:445-450 */
+            const float a_us = F(3e-5) * (0.5f * (1.0f - tanhf((V - F(-83.0)) / F(23.0))));
+            const float b_us = F(1e-5) * (0.5f * (1.0f + tanhf((V - F(-83.0 + 30)) / F(23.0))));
+            us_out[i] = rush_larsen(us_in[i], a_us / (a_us + b_us), RCP(a_us + b_us), mdt_s);   /* :198-199 */
+            i_Na = i_Na * us_in[i];                                                              /* :221-222 */
+        }
         const float i_NaCa = q.i_NaCaa * powf(s[cNa_i], 3.0f) - q.i_NaCab * s[cCa_i];
         const float i_B_Na = F(Cm * g_B_Na) * (V - E_Na);
         o[cNa_i * n] = s[cNa_i] + ((-3.0f * i_NaK - ((3.0f * i_NaCa + i_B_Na) + i_Na)) / ViF) * dtf;
@@ -611,6 +630,28 @@ void orc_court_ultra_run(int H, int W, double dt, double diff, const float *phi,
         orc_court_step_rate(H, W, dt, diff, phi, chronic, 1.0, slab, tmp, scr);
         memcpy(slab, tmp, COURT_NVAR * n * sizeof(float));
     }
+}
+
+/* court_ultra.py with config['ultra_slow']: 22 arrays, `_us_` last.  slab [22][H][W]; tmp [22][H][W] + 2*H*W */
+void orc_court_ultra_us_run(int H, int W, double dt, double diff, const float *phi, int chronic, float *slab,
+                            float *tmp, int nticks)
+{
+    const long n = (long)H * W;
+    float *scr = tmp + (COURT_NVAR + 1) * n;
+    for (int t = 0; t < nticks; ++t) {
+        court_step_impl(H, W, dt, diff, phi, chronic, 1.0, slab, tmp, scr, slab + COURT_NVAR * n,
+                        tmp + COURT_NVAR * n);
+        memcpy(slab, tmp, (COURT_NVAR + 1) * n * sizeof(float));
+    }
+}
+
+/* the two extra intermediates of court_ultra.py:445-450 for one voltage */
+void orc_court_us_inter(float V, float *us_inf, float *tau_us)
+{
+    const float a_us = F(3e-5) * (0.5f * (1.0f - tanhf((V - F(-83.0)) / F(23.0))));
+    const float b_us = F(1e-5) * (0.5f * (1.0f + tanhf((V - F(-83.0 + 30)) / F(23.0))));
+    *us_inf = a_us / (a_us + b_us);
+    *tau_us = RCP(a_us + b_us);
 }
 
 int orc_num_threads(void)

@@ -344,10 +344,11 @@ def court_traj(name, H, W, diff, holes, ticks, snaps, s2=None):
     save(name, **out)
 
 
-def court_ultra_traj(name, H, W, diff, holes, ticks, snaps, s2=None):
+def court_ultra_traj(name, H, W, diff, holes, ticks, snaps, s2=None, ultra_slow=False):
     """court_ultra.py: every tick assigns all variables with dt (court_ultra.py:107-111,127-128);
-    config['ultra_slow'] = False as in its own __main__ (court_ultra.py:543)"""
-    m = court_ultra.Courtemanche(cfg(H, W, diff, ultra_slow=False))
+    config['ultra_slow'] = False as in its own __main__ (court_ultra.py:543), or True for the
+    22-variable model with the `_us_` gate (court_ultra.py:81-82,198-199,221-222,445-450)"""
+    m = court_ultra.Courtemanche(cfg(H, W, diff, ultra_slow=ultra_slow))
     for h in holes:
         m.add_hole_to_phase_field(*h)
     out = {'phase': m.phase, 'diff': diff, 'dt': 0.1}
@@ -374,6 +375,14 @@ def court_ultra_traj(name, H, W, diff, holes, ticks, snaps, s2=None):
                     out['%s_t%d' % (k, i + 1)] = np.array(state[k])
     out['snap_ticks'] = np.array(sorted(snaps))
     out['names'] = np.array(names)
+    if ultra_slow:
+        # the two extra intermediates on a voltage sweep (court_ultra.py:445-450), via the reference's own calc_inter
+        vs = np.linspace(-100, 50, 301).astype(f32)
+        with np.errstate(all='ignore'):
+            inter = m.calc_inter(T(vs), tf)
+        out['us_sweep_V'] = vs
+        out['us_sweep_us_infinity'] = np.array(inter['us_infinity'].a)
+        out['us_sweep_tau_us'] = np.array(inter['tau_us'].a)
     save(name, **out)
 
 
@@ -381,6 +390,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'court_ultra':
         court_ultra_traj('court_ultra_traj', 48, 56, 1.5, [(28, 24, 5), (28, 24, 22, True)], 120, {1, 10, 60, 120},
                          s2=(50, 'luq', 10.0))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'court_ultra_us':
+        court_ultra_traj('court_ultra_us_traj', 40, 48, 1.5, [(24, 20, 5)], 120, {1, 10, 60, 120},
+                         s2=(50, 'luq', 10.0), ultra_slow=True)
         return
     unit_ops()
     fenton_step()
@@ -404,6 +417,8 @@ def main():
                {1, 11, 60}, s2=(30, 'luq', 10.0))
     court_ultra_traj('court_ultra_traj', 48, 56, 1.5, [(28, 24, 5), (28, 24, 22, True)], 120, {1, 10, 60, 120},
                      s2=(50, 'luq', 10.0))
+    court_ultra_traj('court_ultra_us_traj', 40, 48, 1.5, [(24, 20, 5)], 120, {1, 10, 60, 120},
+                     s2=(50, 'luq', 10.0), ultra_slow=True)
 
 
 if __name__ == '__main__':

@@ -478,8 +478,73 @@ def test_court_ultra_trajectory(gpu_lib, golden, policy, tmp_path):
     m2.define(state=st)
     for k in m.VAR_NAMES:
         assert np.array_equal(m2._State[k].eval(), m.state[k])
-    with pytest.raises(NotImplementedError):
-        court_ultra.Courtemanche(cfg(H, W, 1.0, policy, ultra_slow=True))
+
+
+@pytest.mark.parametrize('policy', POLICIES)
+def test_court_ultra_slow_gate(gpu_lib, golden, orc, policy, capsys):
+    """config['ultra_slow']=True: the 22-array model with the `_us_` gate (court_ultra.py:81-82,198-199,221-222,
+    445-450), its two extra intermediates and the ϕ-weighted observer (court_ultra.py:465-486)"""
+    from fib_tf_amd import court_ultra
+    f = golden('court_ultra_us_traj')
+    H, W = f['phase'].shape
+    m = court_ultra.Courtemanche(cfg(H, W, float(f['diff']), policy, ultra_slow=True))
+    m.phase = f['phase']
+    m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
+    assert m.VAR_NAMES[-1] == '_us_' and len(m.VAR_NAMES) == 22
+    for k in m.VAR_NAMES:
+        assert np.array_equal(m._State[k].eval(), f['init_' + k])
+    t0 = 0
+
+    def hook(i):
+        if i + t0 == 50:
+            m.fire_op('s2')
+
+    # _u_/_v_: the SR-release sigmoids (width 1.367e-15 in Fn) amplify ulps of the currents; the oracle shows
+    # 1.1e-5 against the same fixture (tests/test_oracle_golden.py)
+    sr = 5.0 if policy == 'exact' else 10.0
+    scales = {'V': 150.0, '_Ca_i_': 1e-3, '_Ca_rel_': 1.5, '_u_': sr, '_v_': sr}
+    for t in [int(x) for x in f['snap_ticks']]:
+        run_to(m, t - t0, hook)
+        t0 = t
+        for k in m.VAR_NAMES:
+            assert_close(m._State[k].eval(), f['%s_t%d' % (k, t)], 2e-5, 'court_ultra_us %s t%d' % (k, t),
+                         scale=scales.get(k, 1.0))
+    # the gate moves ~1e-7 per step: compare the accumulated change itself, not just the value
+    us, ref = m._State['_us_'].eval(), f['_us__t120']
+    assert np.max(np.abs(us - ref)) <= (2e-7 if policy == 'exact' else 2e-6)
+    # calc_inter on the device vs the reference's sweep and the oracle
+    inter = m.calc_inter(f['us_sweep_V'])
+    tol = 2e-6 if policy == 'exact' else 2e-4
+    # 1 - tanh(x) cancels for V >> -83 mV: an absolute ulp(1) of tanh is all that can be asked of us_infinity
+    assert np.allclose(inter['us_infinity'], f['us_sweep_us_infinity'], rtol=tol, atol=3e-7 if policy == 'exact' else 3e-6)
+    assert np.allclose(inter['tau_us'], f['us_sweep_tau_us'], rtol=tol, atol=0)
+    # observer: 7 columns with ultra_slow (court_ultra.py:482)
+    rows = []
+    court_ultra.cl_observer(m, rows, 1000, 5, 77)
+    assert len(rows) == 1 and len(rows[0]) == 7 and rows[0][:2] == [1005, 77]
+    assert abs(rows[0][4] - np.average(us, weights=m.phase)) < 1e-6
+    assert abs(rows[0][5] - np.average(m._Inter['us_infinity'].eval(), weights=m.phase)) < 1e-6
+    assert '1005:' in capsys.readouterr().out
+
+
+@pytest.mark.parametrize('policy', POLICIES)
+def test_court_calc_inter_device(gpu_lib, golden, orc, policy):
+    """Courtemanche.calc_inter evaluated by the device code: against the oracle on a voltage sweep that
+    includes the neighbourhoods of every removable singularity, and against generate_table's values at -50 mV"""
+    from fib_tf_amd import _lib
+    vs = np.concatenate([np.linspace(-100, 50, 601), [-10.0001, 7.9, -47.13, -40.0, -14.1, 3.3328, 19.9, -50.0]]).astype(np.float32)
+    got = _lib.court_inter(vs, fast=(policy == 'fast'))
+    order = ('d_infinity', 'f_infinity', 'tau_w', 'tau_d', 'tau_f', 'w_infinity', 'm_inf', 'h_inf', 'j_inf', 'tau_oa',
+             'tau_oi', 'tau_ua', 'tau_ui', 'tau_xr', 'tau_xs', 'tau_m', 'tau_h', 'tau_j', 'oa_infinity', 'oi_infinity',
+             'ua_infinity', 'ui_infinity', 'xr_infinity', 'xs_infinity', 'g_Kur', 'f_NaK', 'i_NaCaa', 'i_NaCab', 'i_K1a',
+             'i_Kra')                                          # courtemanche.h:105-134 order = orc_court_calc_inter
+    want = np.stack([orc.court_calc_inter(float(v)) for v in vs], axis=1)          # [30, n]
+    tol = 3e-6 if policy == 'exact' else 3e-4
+    for k, name in enumerate(order):
+        w, g = want[k], got[name]
+        ok = np.abs(g - w) <= tol * np.maximum(np.abs(w), 1e-30)
+        assert ok.all(), (name, vs[~ok][:5], g[~ok][:5], w[~ok][:5])
 
 
 def test_run_with_screen_and_cycle_length_observer(gpu_lib, tmp_path):

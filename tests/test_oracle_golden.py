@@ -188,3 +188,31 @@ def test_court_ultra_trajectory(orc, golden):
         t0 = t
         for i, k in enumerate(orc.COURT_VARS):
             close(slab[i], f['%s_t%d' % (k, t)], 1e-5, {'V': 150.0, '_Ca_i_': 1e-3}.get(k, 1.0), 'ultra %s t%d' % (k, t))
+
+
+def test_court_ultra_us_trajectory(orc, golden):
+    """court_ultra.py with config['ultra_slow']=True: 22 arrays, `_us_` scales i_Na"""
+    from fib_tf_amd.ionic import IonicModel
+    f = golden('court_ultra_us_traj')
+    H, W = f['phase'].shape
+    names = [str(x) for x in f['names']]
+    assert names == list(orc.COURT_VARS) + ['_us_']
+    rect = IonicModel({'height': H, 'width': W}).pace_rect('luq')
+    slab = np.stack([f['init_' + k] for k in names]).copy()
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        for i in range(t0, t):
+            orc.court_ultra_us_run(slab, 0.1, float(f['diff']), f['phase'], True, 1)
+            if i == 50:
+                slab[0] = orc.pace(slab[0], *rect, 10.0, -100.0)
+        t0 = t
+        for i, k in enumerate(names):
+            # _u_/_v_: the SR-release sigmoids (width 1.367e-15 in Fn) amplify libm-vs-stand-in ulps of the currents
+            close(slab[i], f['%s_t%d' % (k, t)], 1e-5, {'V': 150.0, '_Ca_i_': 1e-3, '_u_': 5.0, '_v_': 5.0}.get(k, 1.0),
+                  'ultra_us %s t%d' % (k, t))
+    # the gate itself: per-step increments are ~1e-7, so it is pinned to a few ulp of 0.72
+    assert np.max(np.abs(slab[21] - f['_us__t120'])) <= 2e-7
+    a, b = orc.court_us_inter(f['us_sweep_V'])
+    # 1 - tanh(x) cancels for V >> -83 mV: one ulp of tanh is an absolute 6e-8 in alpha_us/3e-5
+    assert np.allclose(a, f['us_sweep_us_infinity'], rtol=3e-6, atol=3e-7)
+    assert np.allclose(b, f['us_sweep_tau_us'], rtol=3e-6, atol=0)
