@@ -90,6 +90,11 @@ class Courtemanche(IonicModel):
                     out[n] = res[i]
         return out
 
+    def calc_inter(self, V, mod=None):
+        """the voltage-only intermediates (court.py:273-429; court_ultra.py:264-452 adds us_infinity, tau_us), evaluated by the device code;
+        `mod` (np / tf in the reference) is accepted and ignored"""
+        return _lib.court_inter(V, fast=bool(getattr(self, 'fast_math', True)), device=self.device)
+
     def pot(self):
         return self._V
 

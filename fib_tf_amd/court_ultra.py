@@ -48,11 +48,6 @@ class Courtemanche(_Courtemanche):
         self._ops['slow'] = ('call', lambda: None)             # tf.group() of nothing, court_ultra.py:110
         self._Inter = {k: _InterVar(self, k) for k in _lib.COURT_INTER_KEYS}
 
-    def calc_inter(self, V, mod=None):
-        """the voltage-only intermediates (court_ultra.py:264-452), evaluated by the device code;
-        `mod` (np / tf in the reference) is accepted and ignored"""
-        return _lib.court_inter(V, fast=bool(getattr(self, 'fast_math', True)), device=self.device)
-
     def _fire_trend(self):
         # only V, at [width//2, height//8] (court_ultra.py:112-116)
         v = self._stepper.probe(0, self.width // 2, self.height // 8)

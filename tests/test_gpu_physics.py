@@ -66,3 +66,20 @@ def test_br_conduction_velocity_ratios(gpu_lib):
     for d in BR_CV:
         got, want = cv[d] / cv[1.0], BR_CV[d] / BR_CV[1.0]
         assert abs(got / want - 1.0) < 0.05, 'diff %.2f: CV ratio %.3f vs reference %.3f' % (d, got, want)
+
+
+def test_two_electrode_estimator_agrees_with_probe_timing(gpu_lib):
+    """fib_tf_amd.egm (the reference's egm.py method: Gaussian electrodes on image(), sampled every ms) measures
+    the same planar-wave velocity as direct probe timing, within the 1 ms sampling of the electrogram"""
+    from fib_tf_amd import egm
+    from fib_tf_amd.fenton import Fenton4v
+    cfg = {'height': 48, 'width': 420, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.0, 'duration': 700}
+    m = Fenton4v(dict(cfg))
+    m.define()
+    want = velocity(m, 0.5)
+    m = Fenton4v(dict(cfg))
+    m.define()
+    tr = egm.record(m, egm.create_mask(m, 150, 24, 5), egm.create_mask(m, 300, 24, 5))
+    assert tr.shape == (700, 2)
+    got = egm.conduction_velocity(tr, 150.0)
+    assert abs(got / want - 1.0) < 0.03, (got, want)

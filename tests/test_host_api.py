@@ -149,3 +149,48 @@ def test_bench_cli_contract():
     for flag in ('--gpus', '--steps', '--warmup'):
         assert flag in src
     assert bench.ALGO_BYTES['fenton'] + 4 == 36 and bench.ALGO_BYTES['br'] + 4 == 68
+
+
+def test_egm_masks_and_delay():
+    """fib_tf_amd.egm host logic (egm.py:5-12 mask; two-electrode delay on synthetic upstrokes)"""
+    from fib_tf_amd import egm
+
+    class M:
+        width, height = 40, 30
+    m = egm.create_mask(M, 12, 7, 5)
+    assert m.dtype == np.float32 and m.shape == (30, 40)
+    assert m[7, 12] == 1.0 and abs(m[7, 17] - np.exp(-1.0)) < 1e-6 and abs(m[2, 12] - np.exp(-1.0)) < 1e-6
+    t = np.arange(200, dtype=np.float64)
+    tr = np.stack([1 / (1 + np.exp(-(t - 50.25))), 3 / (1 + np.exp(-(t - 80.75)))], axis=1)
+    assert abs(egm.delay_ms(tr, every_ms=1.0) - 30.5) < 0.05
+    assert abs(egm.conduction_velocity(tr, 61.0, every_ms=0.5) - 4.0) < 0.02
+    with pytest.raises(ValueError):
+        egm.delay_ms(np.zeros((10, 2)))
+
+
+def test_playcube_and_png_writer(tmp_path):
+    """fib_tf_amd.playcube replays a cube through the headless Screen; PNG frames decode back (zlib) to the
+    8-bit grey image"""
+    import struct
+    import zlib
+    from fib_tf_amd import playcube
+    rng = np.random.default_rng(5)
+    cube = rng.random((4, 6, 9)).astype(np.float32)
+    np.save(tmp_path / 'cube.npy', cube)
+    sc = playcube.play(str(tmp_path / 'cube.npy'), loops=2, delay=0, png_pattern=str(tmp_path / 'f%02d.png'))
+    assert sc.count == 8 and np.array_equal(sc.last, cube[3])
+    raw = (tmp_path / 'f05.png').read_bytes()
+    assert raw[:8] == b'\x89PNG\r\n\x1a\n'
+    w, h, depth, ctype = struct.unpack('>IIBB', raw[16:26])
+    assert (w, h, depth, ctype) == (9, 6, 8, 0)
+    pos, idat = 8, b''
+    while pos < len(raw):
+        n, tag = struct.unpack('>I4s', raw[pos:pos + 8])
+        if tag == b'IDAT':
+            idat += raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(6, 10)[:, 1:]
+    assert np.max(np.abs(px.astype(np.float32) / 255.0 - cube[1])) <= 0.5 / 255 + 1e-6
+    with pytest.raises(ValueError):
+        playcube.play(np.zeros((3, 3)))
+    playcube.main([str(tmp_path / 'cube.npy'), '--delay', '0'])
