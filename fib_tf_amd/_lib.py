@@ -14,7 +14,7 @@ SO = os.path.join(HERE, 'libfibhip.so')
 SRC = os.path.join(HERE, 'csrc', 'fibhip.hip')
 HDR = os.path.join(ROOT, 'include', 'fibhip.h')
 
-FENTON4V, BR, COURT, COURT_US = 0, 1, 2, 3
+FENTON4V, BR, COURT, COURT_US, CUSTOM = 0, 1, 2, 3, 4
 CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED = 1, 2, 4, 8, 16, 32
 
 # -ffp-contract=off: FMAs appear only where the source writes them (policy hook P::mad).
@@ -54,6 +54,7 @@ SYMBOLS = {
     'fibhip_set_consts': ([_h, _fp, C.c_int], C.c_int),
     'fibhip_step': ([_h, C.c_int], C.c_int),
     'fibhip_step_slow': ([_h], C.c_int),
+    'fibhip_step_mode': ([_h, C.c_int], C.c_int),
     'fibhip_pace': ([_h, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float], C.c_int),
     'fibhip_probe': ([_h, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'fibhip_sync': ([_h], C.c_int),
@@ -75,10 +76,13 @@ SYMBOLS = {
 _lib = None
 
 
+DEPS = [SRC, HDR] + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "models.hpp", "fenton_step.inc", "br_step.inc",
+                                                             "court_step.inc", "court_inter.inc")]
+
+
 def build(force=False, verbose=False):
     """compile csrc/fibhip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
-    deps = [SRC, HDR] + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "models.hpp", "fenton_step.inc", "br_step.inc", "court_step.inc", "court_inter.inc")]
-    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in DEPS):
         return SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc] + HIPCC_FLAGS + [SRC, '-o', SO]
@@ -88,25 +92,44 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_custom(inc_path, so_path, verbose=False):
+    """the same translation unit with ONE traced model compiled in (generated header `inc_path`,
+    fib_tf_amd/traced.py) and the stock models' kernels left out: a few seconds instead of a minute"""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tmp = '%s.%d.tmp' % (so_path, os.getpid())
+    cmd = [hipcc] + HIPCC_FLAGS + ['-DFIB_CUSTOM_ONLY', '-DFIB_CUSTOM_MODEL_INC="%s"' % os.path.abspath(inc_path),
+                                   SRC, '-o', tmp]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, so_path)            # atomic: several ranks may build the same model at once
+    return so_path
+
+
+def load(path):
+    """dlopen a build of the library and declare every symbol's signature"""
+    L = C.CDLL(path)
+    for name, (args, res) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = args, res
+    if L.fibhip_abi_version() != 1:
+        raise FibhipError('%s: ABI version mismatch' % os.path.basename(path))
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO):
             raise FibhipError('libfibhip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"`); '
                               'fib_tf_amd has no CPU fallback')
-        L = C.CDLL(SO)
-        for name, (args, res) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.argtypes, fn.restype = args, res
-        if L.fibhip_abi_version() != 1:
-            raise FibhipError('libfibhip.so ABI version mismatch')
-        _lib = L
+        _lib = load(SO)
     return _lib
 
 
-def check(rc):
+def check(rc, L=None):
     if rc < 0:
-        raise FibhipError(lib().fibhip_last_error().decode('utf-8', 'replace'))
+        raise FibhipError((L or lib()).fibhip_last_error().decode('utf-8', 'replace'))
     return rc
 
 
@@ -149,8 +172,9 @@ class Stepper:
     """One fibhip handle: a grid (or a row block of it) resident on one MI355X."""
 
     def __init__(self, model, height, width, dt, diff, flags=0, device=0, steps_per_tick=0,
-                 global_height=0, row_offset=0, ghost_top=0, ghost_bottom=0, stream=None, ext_slabs=None):
-        L = lib()
+                 global_height=0, row_offset=0, ghost_top=0, ghost_bottom=0, stream=None, ext_slabs=None,
+                 library=None):
+        L = library or lib()
         d = Desc()
         d.struct_size = C.sizeof(Desc)
         d.model, d.height, d.width = model, height, width
@@ -162,11 +186,14 @@ class Stepper:
         if ext_slabs is not None:
             d.ext_slab[0], d.ext_slab[1] = ext_slabs
         self._h = _h()
-        self.nvar = check(L.fibhip_nvar(model))
-        self.height, self.width = height, width
-        self.steps_per_tick = steps_per_tick or check(L.fibhip_default_steps_per_tick(model))
-        check(L.fibhip_create(C.byref(d), C.byref(self._h)))
         self._L = L
+        self.nvar = self._ck(L.fibhip_nvar(model))
+        self.height, self.width = height, width
+        self.steps_per_tick = steps_per_tick or self._ck(L.fibhip_default_steps_per_tick(model))
+        self._ck(L.fibhip_create(C.byref(d), C.byref(self._h)))
+
+    def _ck(self, rc):
+        return check(rc, self._L)
 
     def close(self):
         if getattr(self, '_h', None) and self._h.value:
@@ -177,74 +204,77 @@ class Stepper:
 
     def set_phase(self, phi):
         if phi is None:
-            check(self._L.fibhip_set_phase(self._h, None))
+            self._ck(self._L.fibhip_set_phase(self._h, None))
         else:
             phi = _f32(phi)
             assert phi.shape == (self.height, self.width)
-            check(self._L.fibhip_set_phase(self._h, _ptr(phi)))
+            self._ck(self._L.fibhip_set_phase(self._h, _ptr(phi)))
 
     def set_state(self, var, arr):
         arr = _f32(arr)
         want = (self.nvar, self.height, self.width) if var < 0 else (self.height, self.width)
         assert arr.shape == want, (arr.shape, want)
-        check(self._L.fibhip_set_state(self._h, var, _ptr(arr)))
+        self._ck(self._L.fibhip_set_state(self._h, var, _ptr(arr)))
 
     def get_state(self, var=-1):
         shape = (self.nvar, self.height, self.width) if var < 0 else (self.height, self.width)
         out = np.empty(shape, np.float32)
-        check(self._L.fibhip_get_state(self._h, var, _ptr(out)))
+        self._ck(self._L.fibhip_get_state(self._h, var, _ptr(out)))
         return out
 
     def set_consts(self, tbl):
         tbl = _f32(tbl).ravel()
-        check(self._L.fibhip_set_consts(self._h, _ptr(tbl), tbl.size))
+        self._ck(self._L.fibhip_set_consts(self._h, _ptr(tbl), tbl.size))
 
     def step(self, nticks=1):
-        check(self._L.fibhip_step(self._h, nticks))
+        self._ck(self._L.fibhip_step(self._h, nticks))
 
     def step_slow(self):
-        check(self._L.fibhip_step_slow(self._h))
+        self._ck(self._L.fibhip_step_slow(self._h))
+
+    def step_mode(self, mode):
+        self._ck(self._L.fibhip_step_mode(self._h, mode))
 
     def pace(self, r0, r1, c0, c1, v, min_v):
-        check(self._L.fibhip_pace(self._h, r0, r1, c0, c1, v, min_v))
+        self._ck(self._L.fibhip_pace(self._h, r0, r1, c0, c1, v, min_v))
 
     def probe(self, var, row, col):
         out = C.c_float()
-        check(self._L.fibhip_probe(self._h, var, row, col, C.byref(out)))
+        self._ck(self._L.fibhip_probe(self._h, var, row, col, C.byref(out)))
         return np.float32(out.value)
 
     def sync(self):
-        check(self._L.fibhip_sync(self._h))
+        self._ck(self._L.fibhip_sync(self._h))
 
     def time_steps(self, nticks):
         ms, n = C.c_float(), C.c_int()
-        check(self._L.fibhip_time_steps(self._h, nticks, C.byref(ms), C.byref(n)))
+        self._ck(self._L.fibhip_time_steps(self._h, nticks, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def step_edges(self):
-        check(self._L.fibhip_step_edges(self._h))
+        self._ck(self._L.fibhip_step_edges(self._h))
 
     def step_interior(self):
-        check(self._L.fibhip_step_interior(self._h))
+        self._ck(self._L.fibhip_step_interior(self._h))
 
     def step_commit(self):
-        check(self._L.fibhip_step_commit(self._h))
+        self._ck(self._L.fibhip_step_commit(self._h))
 
     def state_buf(self, var):
         p = C.c_void_p()
-        return check(self._L.fibhip_state_ptr(self._h, var, C.byref(p))), p.value
+        return self._ck(self._L.fibhip_state_ptr(self._h, var, C.byref(p))), p.value
 
     def next_buf(self, var):
         p = C.c_void_p()
-        return check(self._L.fibhip_next_ptr(self._h, var, C.byref(p))), p.value
+        return self._ck(self._L.fibhip_next_ptr(self._h, var, C.byref(p))), p.value
 
     def halo_vars(self):
-        return check(self._L.fibhip_halo_vars(self._h))
+        return self._ck(self._L.fibhip_halo_vars(self._h))
 
     def halo_due(self):
-        return bool(check(self._L.fibhip_halo_due(self._h)))
+        return bool(self._ck(self._L.fibhip_halo_due(self._h)))
 
     def launch_plan(self):
         k, n = C.c_int(), C.c_int()
-        check(self._L.fibhip_launch_plan(self._h, C.byref(k), C.byref(n)))
+        self._ck(self._L.fibhip_launch_plan(self._h, C.byref(k), C.byref(n)))
         return k.value, n.value

@@ -138,6 +138,14 @@ struct Variant {
 // (tuning sweeps).  Tile shapes: K=1 tiles are wide (coalesced 256-B rows); K>1 tiles are square-ish
 // to keep the redundant rim small.
 static const Variant g_variants[] = {
+#ifdef FIB_CUSTOM_MODEL_INC
+    // ---- the traced model this copy of the library was built for (constants from the generated header) ----
+    V4(Custom, FIBHIP_CUSTOM, 0, 1, 64, 4, 256),
+#if FIB_CUSTOM_K > 1
+    S4(Custom, FIBHIP_CUSTOM, 0, FIB_CUSTOM_K, FIB_CUSTOM_TX, FIB_CUSTOM_TY, FIB_CUSTOM_R),
+#endif
+#endif
+#ifndef FIB_CUSTOM_ONLY
     // ---- Fenton 4v ----
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
@@ -184,6 +192,7 @@ static const Variant g_variants[] = {
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
     // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
     V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
+#endif
 };
 static const int g_nvariants = (int)(sizeof g_variants / sizeof g_variants[0]);
 
@@ -215,6 +224,9 @@ struct fibhip_ctx {
     Fenton::Consts kf;
     BeelerReuter::Consts kb;
     Courtemanche::Consts kc;
+#ifdef FIB_CUSTOM_MODEL_INC
+    Custom::Consts ku;
+#endif
     std::vector<PlanItem> plan;
     hipEvent_t ev_main, ev_int, ev_t0, ev_t1;
     int phase_of_tick;      // 0 idle, 1 edges issued, 2 interior issued
@@ -232,6 +244,9 @@ static const void *consts_of(fibhip_ctx *h)
     switch (h->d.model) {
     case FIBHIP_FENTON4V: return &h->kf;
     case FIBHIP_BR: return &h->kb;
+#ifdef FIB_CUSTOM_MODEL_INC
+    case FIBHIP_CUSTOM: return &h->ku;
+#endif
     default: return &h->kc;
     }
 }
@@ -243,6 +258,9 @@ extern "C" int fibhip_nvar(int model)
     case FIBHIP_BR: return BeelerReuter::NVAR;
     case FIBHIP_COURT: return Courtemanche::NVAR;
     case FIBHIP_COURT_US: return CourtemancheUS::NVAR;
+#ifdef FIB_CUSTOM_MODEL_INC
+    case FIBHIP_CUSTOM: return Custom::NVAR;
+#endif
     default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
     }
 }
@@ -254,6 +272,9 @@ extern "C" int fibhip_default_steps_per_tick(int model)
     case FIBHIP_BR: return BeelerReuter::DEFAULT_STEPS;
     case FIBHIP_COURT: return Courtemanche::DEFAULT_STEPS;
     case FIBHIP_COURT_US: return CourtemancheUS::DEFAULT_STEPS;
+#ifdef FIB_CUSTOM_MODEL_INC
+    case FIBHIP_CUSTOM: return Custom::DEFAULT_STEPS;
+#endif
     default: return fail(FIBHIP_EINVAL, "unknown model %d", model);
     }
 }
@@ -302,6 +323,9 @@ static int build_plan(fibhip_ctx *h)
         // smaller rim when there are many tiles per CU (throughput-bound), fatter waves when there are
         // very many (occupancy).
         prefK = 1;
+#ifdef FIB_CUSTOM_MODEL_INC
+        if (h->d.model == FIBHIP_CUSTOM) prefK = FIB_CUSTOM_K;
+#endif
         if (h->d.model == FIBHIP_FENTON4V) {
             // rows of the largest launch: the first tick of an exchange cycle also advances the ghost rows
             const int ext = (h->cycle - 1) * h->spt;
@@ -768,12 +792,10 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     return 0;
 }
 
-extern "C" int fibhip_step_slow(fibhip_t h)
+// re-evaluation of the model on the current state, in place, without the stencil: assigns mask(mode)
+static int run_pointwise_mode(fibhip_t h, launch_fn fn)
 {
-    NEED(h);
-    if (h->d.model != FIBHIP_COURT) return fail(FIBHIP_EINVAL, "step_slow: Courtemanche only");
-    if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
-    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_slow inside an open tick");
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_mode inside an open tick");
     LaunchCtx c;
     for (int v = 0; v < h->nvar; ++v) {
         c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;
@@ -781,17 +803,56 @@ extern "C" int fibhip_step_slow(fibhip_t h)
     }
     c.consts = consts_of(h);
     c.g = base_geo(h);
-    // the ghost rows that later ticks of this cycle still advance must get the slow update too
+    // the ghost rows that later ticks of this cycle still advance must get the update too
     const int live = (h->cpos == 0 ? h->cycle : h->cycle - h->cpos) * h->spt;
     c.g.r0 = imax(0, h->own0 - (h->d.ghost_top ? live : 0));
     c.g.r1 = imin(h->d.height, h->own1 + (h->d.ghost_bottom ? live : 0));
     c.sub0 = 0;
-    const bool fast = (h->d.flags & FIBHIP_FAST) != 0;
-    launch_fn slow_fn = fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
-                             : launch_pointwise<Courtemanche, Exact, Courtemanche::MODE_SLOW>;
-    HIPCHK(slow_fn(h->s0, c));
+    HIPCHK(fn(h->s0, c));
     h->launches++;
     return 0;
+}
+
+#ifdef FIB_CUSTOM_MODEL_INC
+template <class P, int M_>
+static launch_fn custom_mode_fn(int mode)
+{
+    if constexpr (M_ >= Custom::NMODES) {
+        return nullptr;
+    } else {
+        if (mode == M_) return launch_pointwise<Custom, P, M_>;
+        return custom_mode_fn<P, M_ + 1>(mode);
+    }
+}
+#endif
+
+extern "C" int fibhip_step_mode(fibhip_t h, int mode)
+{
+    NEED(h);
+    const bool fast = (h->d.flags & FIBHIP_FAST) != 0;
+    (void)fast;
+#ifdef FIB_CUSTOM_MODEL_INC
+    if (h->d.model == FIBHIP_CUSTOM) {
+        launch_fn fn = mode >= 1 ? (fast ? custom_mode_fn<Fast, 1>(mode) : custom_mode_fn<Exact, 1>(mode)) : nullptr;
+        if (!fn) return fail(FIBHIP_EINVAL, "step_mode: the traced model has no mode %d", mode);
+        return run_pointwise_mode(h, fn);
+    }
+#endif
+#ifndef FIB_CUSTOM_ONLY
+    if (h->d.model == FIBHIP_COURT && mode == Courtemanche::MODE_SLOW) {
+        if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
+        return run_pointwise_mode(h, fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
+                                          : launch_pointwise<Courtemanche, Exact, Courtemanche::MODE_SLOW>);
+    }
+#endif
+    return fail(FIBHIP_EINVAL, "step_mode: model %d has no mode %d", h->d.model, mode);
+}
+
+extern "C" int fibhip_step_slow(fibhip_t h)
+{
+    NEED(h);
+    if (h->d.model != FIBHIP_COURT) return fail(FIBHIP_EINVAL, "step_slow: Courtemanche only");
+    return fibhip_step_mode(h, Courtemanche::MODE_SLOW);
 }
 
 extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, float min_v)

@@ -62,8 +62,33 @@ template <int R, class F> FIB_DEV vf<R> vmap(const vf<R> &a, F f)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r]); return o; }
 template <int R, class F> FIB_DEV vf<R> vzip(const vf<R> &a, const vf<R> &b, F f)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r], b.v[r]); return o; }
+template <int R, class F> FIB_DEV vf<R> vzip(const vf<R> &a, float b, F f)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a.v[r], b); return o; }
 template <int R, class F> FIB_DEV vf<R> vzip(float a, const vf<R> &b, F f)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = f(a, b.v[r]); return o; }
+#define FIB_VEC_CMP(NAME, OP)                                                                \
+    template <int R> FIB_DEV vm<R> NAME(const vf<R> &a, const vf<R> &b)                      \
+    { vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] OP b.v[r]; return o; }   \
+    template <int R> FIB_DEV vm<R> NAME(const vf<R> &a, float b)                              \
+    { vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] OP b; return o; }        \
+    template <int R> FIB_DEV vm<R> NAME(float a, const vf<R> &b)                              \
+    { vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a OP b.v[r]; return o; }        \
+    FIB_DEV bool NAME(float a, float b) { return a OP b; }
+FIB_VEC_CMP(vcmp_gt, >)
+FIB_VEC_CMP(vcmp_ge, >=)
+FIB_VEC_CMP(vcmp_lt, <)
+FIB_VEC_CMP(vcmp_le, <=)
+FIB_VEC_CMP(vcmp_eq, ==)
+FIB_VEC_CMP(vcmp_ne, !=)
+template <int R> FIB_DEV vm<R> vm_and(const vm<R> &a, const vm<R> &b)
+{ vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] && b.v[r]; return o; }
+template <int R> FIB_DEV vm<R> vm_or(const vm<R> &a, const vm<R> &b)
+{ vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = a.v[r] || b.v[r]; return o; }
+template <int R> FIB_DEV vm<R> vm_not(const vm<R> &a)
+{ vm<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = !a.v[r]; return o; }
+FIB_DEV bool vm_and(bool a, bool b) { return a && b; }
+FIB_DEV bool vm_or(bool a, bool b) { return a || b; }
+FIB_DEV bool vm_not(bool a) { return !a; }
 template <class T> struct bcast;
 template <> struct bcast<float> { static FIB_DEV float of(float x) { return x; } };
 template <int R> struct bcast<vf<R>> { static FIB_DEV vf<R> of(float x) { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = x; return o; } };
@@ -109,6 +134,9 @@ struct Exact {
     template <class T> static FIB_DEV T exp(const T &a) { return vmap(a, [](float x) { return expf(x); }); }
     template <class T> static FIB_DEV T expm1(const T &a) { return vmap(a, [](float x) { return expm1f(x); }); }
     template <class T> static FIB_DEV T log(const T &a) { return vmap(a, [](float x) { return logf(x); }); }
+    // generated code (traced models): division by an arbitrary constant stays a true IEEE division here
+    template <class T> static FIB_DEV T divk(const T &a, float c) { return vmap(a, [c](float x) { return x / c; }); }
+    template <class T> static FIB_DEV T expm1g(const T &a) { return expm1(a); }
     static FIB_DEV float tanh(float a) { return tanhf(a); }   // == tanhv<float>
     static FIB_DEV float sqrt(float a) { return sqrtf(a); }
 };
@@ -149,6 +177,17 @@ struct Fast {
     // ~1 ulp(1) = 6e-8, which is below the float32 resolution of the gate value it multiplies into.
     template <class T> static FIB_DEV T expm1(const T &a) { return exp(a) - 1.0f; }
     template <class T> static FIB_DEV T log(const T &a) { return vmap(a, [](float x) { return __logf(x); }); }
+    template <class T> static FIB_DEV T divk(const T &a, float c) { return a * (1.0f / c); }
+    // expm1 for arbitrary user expressions: exp(x)-1 loses everything for |x| << 1, so small arguments take
+    // the cubic Taylor form (relative error < 1e-7 below 0.03)
+    template <class T> static FIB_DEV T expm1g(const T &a)
+    {
+        return vmap(a, [](float x) {
+            const float big = __expf(x) - 1.0f;
+            const float small = x * __builtin_fmaf(x, __builtin_fmaf(x, 0.16666667f, 0.5f), 1.0f);
+            return fabsf(x) < 0.03f ? small : big;
+        });
+    }
     static FIB_DEV float tanh(float a) { return tanhv<float>(a); }
     static FIB_DEV float sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 };
@@ -157,6 +196,16 @@ static FIB_DEV float sgnf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 static FIB_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 template <int R> static FIB_DEV vf<R> clipf(const vf<R> &x, float lo, float hi)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = fminf(fmaxf(x.v[r], lo), hi); return o; }
+
+// pointwise ops of the traced-model code generator (fib_tf_amd/traced.py), over float and vf<R>
+template <class T> static FIB_DEV T g_sign(const T &a) { return vmap(a, [](float x) { return sgnf(x); }); }
+template <class T> static FIB_DEV T g_abs(const T &a) { return vmap(a, [](float x) { return fabsf(x); }); }
+template <class A, class B> static FIB_DEV auto g_max(const A &a, const B &b)
+{ return vzip(a, b, [](float x, float y) { return fmaxf(x, y); }); }
+template <class A, class B> static FIB_DEV auto g_min(const A &a, const B &b)
+{ return vzip(a, b, [](float x, float y) { return fminf(x, y); }); }
+template <class T> static FIB_DEV T g_pow(const T &a, float e) { return vmap(a, [e](float x) { return powf(x, e); }); }
+template <class P, class T> static FIB_DEV T g_sqrt(const T &a) { return vmap(a, [](float x) { return P::sqrt(x); }); }
 
 // (1 + sign(x)) * 0.5 and (1 - sign(x)) * 0.5 (fenton.py:73-79): the three values {0, 0.5, 1}, produced as
 // clamp(0.5 +- x * 2^27, 0, 1) — one instruction, no compare (compares write SGPRs and issue at ~60 %
@@ -368,5 +417,13 @@ struct CourtT {
 };
 using Courtemanche = CourtT<false>;
 using CourtemancheUS = CourtT<true>;
+
+// =====================================================================================
+// A model traced from a user's reference-style Python file (fib_tf_amd/traced.py) is emitted as
+// `struct Custom` into a generated header and compiled in here (FIBHIP_CUSTOM).
+// =====================================================================================
+#ifdef FIB_CUSTOM_MODEL_INC
+#include FIB_CUSTOM_MODEL_INC
+#endif
 
 }  // namespace fib

@@ -53,11 +53,12 @@ class HipEngine:
     """the product engine: a fibhip handle on torch-owned device slabs and torch's current stream"""
 
     def __init__(self, model_id, height, width, dt, diff, flags, steps_per_tick, global_height, row_offset,
-                 ghost_top, ghost_bottom, device):
+                 ghost_top, ghost_bottom, device, library=None):
         import torch
         self.torch = torch
         self.dev = torch.device('cuda', device)
-        nvar = _lib.check(_lib.lib().fibhip_nvar(model_id))
+        L = library or _lib.lib()
+        nvar = _lib.check(L.fibhip_nvar(model_id), L)
         # row-interleaved slab [rows][nvar][width] (FIBHIP_ROW_INTERLEAVED): the g halo rows of ALL arrays
         # are one contiguous block, i.e. one RCCL message per neighbour and direction
         self.interleaved = True
@@ -70,7 +71,7 @@ class HipEngine:
         self.st = _lib.Stepper(model_id, height, width, dt, diff, flags=flags | _lib.ROW_INTERLEAVED, device=device,
                                steps_per_tick=steps_per_tick, global_height=global_height, row_offset=row_offset,
                                ghost_top=ghost_top, ghost_bottom=ghost_bottom, stream=stream,
-                               ext_slabs=(self.slabs[0].data_ptr(), self.slabs[1].data_ptr()))
+                               ext_slabs=(self.slabs[0].data_ptr(), self.slabs[1].data_ptr()), library=library)
         self.nvar = nvar
 
     # thin forwards
@@ -102,7 +103,7 @@ class ShardedStepper:
     """same surface as `_lib.Stepper`, for one row block of a grid shared by all ranks"""
 
     def __init__(self, model_id, height, width, dt, diff, flags=0, device=0, steps_per_tick=0,
-                 engine_factory=None, group=None, halo_ticks=4):
+                 engine_factory=None, group=None, halo_ticks=4, library=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -111,9 +112,9 @@ class ShardedStepper:
         self.height = height                               # global, like Stepper.height for one device
         L = None
         if engine_factory is None:
-            L = _lib.lib()
-            nvar = _lib.check(L.fibhip_nvar(model_id))
-            spt = steps_per_tick or _lib.check(L.fibhip_default_steps_per_tick(model_id))
+            L = library or _lib.lib()
+            nvar = _lib.check(L.fibhip_nvar(model_id), L)
+            spt = steps_per_tick or _lib.check(L.fibhip_default_steps_per_tick(model_id), L)
         else:
             nvar, spt = engine_factory.nvar(model_id), steps_per_tick or engine_factory.default_steps(model_id)
         self.nvar, self.steps_per_tick = nvar, spt
@@ -131,8 +132,12 @@ class ShardedStepper:
         self.gb = self.g if self.rank < self.world - 1 else 0
         self.lo = self.row0 - self.gt                       # global row of local row 0
         self.lh = self.rows + self.gt + self.gb             # local slab height
-        factory = engine_factory or HipEngine
-        self.eng = factory(model_id, self.lh, width, dt, diff, flags, spt, height, self.lo, self.gt, self.gb, device)
+        if engine_factory is None:
+            self.eng = HipEngine(model_id, self.lh, width, dt, diff, flags, spt, height, self.lo, self.gt, self.gb, device,
+                                 library=library)
+        else:
+            self.eng = engine_factory(model_id, self.lh, width, dt, diff, flags, spt, height, self.lo, self.gt, self.gb,
+                                      device)
         self.halo_n = self.eng.halo_vars()
         self.up = self.rank - 1 if self.rank > 0 else None
         self.down = self.rank + 1 if self.rank < self.world - 1 else None
@@ -251,6 +256,9 @@ class ShardedStepper:
 
     def step_slow(self):
         self.eng.step_slow()                                # pointwise: no halo needed
+
+    def step_mode(self, mode):
+        self.eng.step_mode(mode)                            # pointwise as well
 
     def pace(self, r0, r1, c0, c1, v, min_v):
         self.eng.pace(r0, r1, c0, c1, v, min_v)             # global rectangle; the kernel offsets rows

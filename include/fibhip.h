@@ -35,8 +35,11 @@ typedef struct fibhip_ctx *fibhip_t;
 
 enum fibhip_model {
     FIBHIP_FENTON4V = 0, FIBHIP_BR = 1, FIBHIP_COURT = 2,
-    FIBHIP_COURT_US = 3   /* court_ultra.py with config['ultra_slow']: a 22nd array `_us_` (court_ultra.py:81-82,  */
+    FIBHIP_COURT_US = 3,  /* court_ultra.py with config['ultra_slow']: a 22nd array `_us_` (court_ultra.py:81-82,  */
                           /* 198-199,221-222,445-450); always single-rate (implies FIBHIP_ALLVARS)                */
+    FIBHIP_CUSTOM = 4     /* a user-written IonicModel subclass in the reference's style, traced by               */
+                          /* fib_tf_amd/traced.py and compiled into its own copy of this library                  */
+                          /* (-DFIB_CUSTOM_MODEL_INC=...); the stock library rejects it                           */
 };
 
 enum fibhip_flags {
@@ -115,6 +118,9 @@ int fibhip_step(fibhip_t h, int nticks);
 /* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and
  * assigns the 17 slow variables.                                                                        */
 int fibhip_step_slow(fibhip_t h);
+/* == sess.run(op) of any further assign group of a traced model (mode >= 1; FIBHIP_COURT: mode 1 is the 'slow'
+ * op): the model is re-evaluated on the current state without the Laplacian and the mode's variables assigned  */
+int fibhip_step_mode(fibhip_t h, int mode);
 
 /* == fire_op(name) of an add_pace_op (ionic.py:144-169): pot = max(pot, s) with s = v inside the GLOBAL
  * rectangle rows [r0,r1) x cols [c0,c1) and min_v outside.                                              */

@@ -1,0 +1,72 @@
+"""shared by the traced-model tests: builds one of tests/models/* and replays a driver schedule on it"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# name -> (module, class, needs install(), dt, diff, pace amplitude)
+MODELS = {
+    'ap': ('aliev_panfilov', 'AlievPanfilov', False, 0.1, 1.0, 1.0),
+    'ms': ('mitchell_schaeffer', 'MitchellSchaeffer', False, 0.1, 1.0, 0.9),
+    'gated': ('gated', 'Gated', True, 0.02, 2.0, 10.0),
+    'mrfhn': ('multirate', 'MultirateFHN', True, 0.1, 1.0, 1.5),
+}
+
+
+def make_model(name, H, W, hole=None, **extra):
+    mod, cls, needs_install, dt, diff, _ = MODELS[name]
+    if needs_install:
+        import fib_tf_amd.tfgraph as tfg
+        tfg.install()                   # `import tensorflow` / `import ionic` of the model file resolve to fib_tf_amd
+    import importlib
+    m = getattr(importlib.import_module('tests.models.' + mod), cls)
+    cfg = {'height': H, 'width': W, 'dt': dt, 'dt_per_plot': 10, 'diff': diff, 'duration': 1000}
+    cfg.update(extra)
+    model = m(cfg)
+    if hole is not None:
+        model.add_hole_to_phase_field(*hole)
+    return model
+
+
+def drive(model, name, ticks, s2_tick=None):
+    """the reference drivers' loop shape (court.py:612-617): 'slow' + 'trend' every 10th tick, S2 once"""
+    amp = MODELS[name][5]
+    model.add_pace_op('s2', 'luq', amp)
+    model.duration = ticks * model.dt_per_step * model.dt + 1e-9
+    trend = []
+    for i in model.run():
+        if name == 'gated' and i % 10 == 0:
+            model.fire_op('slow')
+            model.fire_op('trend')
+            trend.append(model._Trend.eval())
+        if s2_tick is not None and i == s2_tick:
+            model.fire_op('s2')
+    state = np.stack([model._State[n].eval() for n in model.VAR_NAMES])
+    return state, np.array(trend, np.float32)
+
+
+def interpret(model, name, ticks, s2_tick=None):
+    """the same schedule through oracle/graph_eval.py (the CPU checker)"""
+    from oracle.graph_eval import Interpreter
+    c = model._analyze()
+    it = Interpreter(c, model.phase)
+    st = np.stack([v.init for v in c['slots']])
+    amp = MODELS[name][5]
+    rect = model.pace_rect('luq')
+    trend = []
+    for i in range(ticks):
+        st = it.run_mode(st, 0)
+        if name == 'gated' and i % 10 == 0:
+            st = it.run_mode(st, 1)
+            r, cc = model.height // 2, 6
+            trend.append([st[model.VAR_NAMES.index('V')][r, cc], st[model.VAR_NAMES.index('c')][r, cc]])
+        if s2_tick is not None and i == s2_tick:
+            r0, r1, c0, c1 = rect
+            s = np.full_like(st[0], np.float32(model.min_v))
+            s[r0:r1, c0:c1] = np.float32(amp)
+            st[0] = np.maximum(st[0], s)                    # ionic.py:125-163
+    return st, np.array(trend, np.float32)
