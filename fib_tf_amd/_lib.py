@@ -106,6 +106,20 @@ def build_custom(inc_path, so_path, verbose=False):
     return so_path
 
 
+def build_specialised(defines, so_path, verbose=False):
+    """the same translation unit with model constants baked in as literals (`defines`: list of -D options);
+    used by BeelerReuter for its Chebyshev table: a VALU operand from a literal issues at full rate, one from an
+    SGPR (kernel argument) at ~60 % (tools/ubench/valu2.hip), and the table feeds 96 multiply-adds per cell-step"""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tmp = '%s.%d.tmp' % (so_path, os.getpid())
+    cmd = [hipcc] + HIPCC_FLAGS + list(defines) + [SRC, '-o', tmp]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, so_path)
+    return so_path
+
+
 def load(path):
     """dlopen a build of the library and declare every symbol's signature"""
     L = C.CDLL(path)
@@ -120,6 +134,10 @@ def load(path):
 def lib():
     global _lib
     if _lib is None:
+        alt = os.environ.get('FIBHIP_LIBRARY')          # tuning experiments: another build of the same source
+        if alt:
+            _lib = load(alt)
+            return _lib
         if not os.path.exists(SO):
             raise FibhipError('libfibhip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"`); '
                               'fib_tf_amd has no CPU fallback')

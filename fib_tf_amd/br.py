@@ -4,10 +4,50 @@ here exactly where the reference keeps it: the α/β coefficient table (br.py:49
 config['cheby'], the definition-time least-squares Chebyshev fits and their change of basis
 (br.py:275-287, 303-332), done in NumPy float64 and handed to the kernel as 12x9 float32
 constants."""
+import os
+
 import numpy as np
 
 from . import _lib
 from .ionic import IonicModel
+
+
+SPEC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_spec')
+_spec_cache = {}
+
+
+def specialised_library(table32, build=True, verbose=False):
+    """libfibhip with the 12x9 Chebyshev table compiled in (csrc/br_step.inc, FIB_BR_TABLE_INC); None when it
+    is neither cached nor buildable here (the caller then stays on the stock library)"""
+    import hashlib
+    import subprocess
+    h = hashlib.sha1(table32.tobytes())
+    for d in _lib.DEPS:
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(_lib.HIPCC_FLAGS).encode())
+    tag = h.hexdigest()[:16]
+    if tag in _spec_cache:
+        return _spec_cache[tag]
+    so = os.path.join(SPEC_DIR, 'libfibhip_br_%s.so' % tag)
+    L = None
+    try:
+        if not os.path.exists(so) and build:
+            os.makedirs(SPEC_DIR, exist_ok=True)
+            inc = os.path.join(SPEC_DIR, 'br_table_%s.inc' % tag)
+            tmp = '%s.%d.tmp' % (inc, os.getpid())
+            with open(tmp, 'w') as f:
+                f.write('// Chebyshev coefficients of fib_tf_amd/br.py chebyshev_table(), float32, row-major 12 x 9\n')
+                f.write('static constexpr float FIB_BR_CHEB[108] = {\n    %s};\n'
+                        % ',\n    '.join(', '.join(float(x).hex() + 'f' for x in row) for row in table32.reshape(12, 9)))
+            os.replace(tmp, inc)
+            _lib.build_specialised(['-DFIB_ONLY_BR', '-DFIB_BR_TABLE_INC="%s"' % inc], so, verbose=verbose)
+        if os.path.exists(so):
+            L = _lib.load(so)
+    except (OSError, subprocess.CalledProcessError) as e:
+        print('fib_tf_amd.br: no specialised build (%s); using the stock library' % e)
+    _spec_cache[tag] = L
+    return L
 
 
 class BeelerReuter(IonicModel):
@@ -80,7 +120,24 @@ class BeelerReuter(IonicModel):
 
     def _configure_stepper(self, st):
         if self.cheby:
-            st.set_consts(self.chebyshev_table().astype(np.float32))   # each coefficient rounded once
+            st.set_consts(self._table32())
+
+    def _table32(self):
+        if getattr(self, '_tbl32', None) is None:
+            self._tbl32 = np.ascontiguousarray(self.chebyshev_table().astype(np.float32))   # each coefficient rounded once
+        return self._tbl32
+
+    def _new_stepper(self, steps_per_tick=0, shard=True):
+        # Chebyshev gates: run a build of the library that has THIS table baked in as literals (same arithmetic,
+        # bit-identical results; +50 % at 512^2 because literal operands issue at full VALU rate and kernel
+        # arguments do not).  Compiled once per table (hipcc, ~15 s) and cached next to the package; without a
+        # compiler the stock library with the table as a kernel argument is used.  config['specialise']=False
+        # forces the stock library.
+        if self.cheby and getattr(self, 'specialise', True) and self._library is None \
+                and getattr(self, 'engine_factory', None) is None and not os.environ.get('FIBHIP_VARIANT'):
+            # (FIBHIP_VARIANT = a tuning sweep over kernel shapes only the stock library carries)
+            self._library = specialised_library(self._table32())
+        return super()._new_stepper(steps_per_tick, shard)
 
     def define(self, s1=True):
         """initial conditions br.py:71-82 (S1: V[:,1] = 10 mV); one tick = 5 sub-steps, with

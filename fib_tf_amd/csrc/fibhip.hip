@@ -144,8 +144,12 @@ static const Variant g_variants[] = {
 #if FIB_CUSTOM_K > 1
     S4(Custom, FIBHIP_CUSTOM, 0, FIB_CUSTOM_K, FIB_CUSTOM_TX, FIB_CUSTOM_TY, FIB_CUSTOM_R),
 #endif
+#if FIB_CUSTOM_K2 > 1 && FIB_CUSTOM_K2 != FIB_CUSTOM_K
+    S4(Custom, FIBHIP_CUSTOM, 0, FIB_CUSTOM_K2, FIB_CUSTOM_TX2, FIB_CUSTOM_TY2, FIB_CUSTOM_R2),
+#endif
 #endif
 #ifndef FIB_CUSTOM_ONLY
+#ifndef FIB_ONLY_BR
     // ---- Fenton 4v ----
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
@@ -167,31 +171,38 @@ static const Variant g_variants[] = {
     V4(Fenton, FIBHIP_FENTON4V, 0, 2, 32, 32, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 4, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
+#endif
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
+    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
+#ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
     S4(BeelerReuter, FIBHIP_BR, 0, 3, 58, 19, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 19, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 2, 60, 19, 3),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
-    V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
+#endif
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
+    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
+#ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
     S4(BeelerReuter, FIBHIP_BR, 1, 3, 58, 19, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 19, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 2, 60, 19, 3),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 5, 32, 32, 512),
-    V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 16, 256),
+#endif
+#ifndef FIB_ONLY_BR
     // ---- Courtemanche (mode 0 fast set, 2 all variables) ----
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 4, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
     // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
     V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
+#endif
 #endif
 };
 static const int g_nvariants = (int)(sizeof g_variants / sizeof g_variants[0]);
@@ -324,8 +335,26 @@ static int build_plan(fibhip_ctx *h)
         // very many (occupancy).
         prefK = 1;
 #ifdef FIB_CUSTOM_MODEL_INC
-        if (h->d.model == FIBHIP_CUSTOM) prefK = FIB_CUSTOM_K;
+        if (h->d.model == FIBHIP_CUSTOM) {
+            // one tile per CU or two: latency-bound, fuse the whole tick; more: throughput-bound (see the generator)
+            const int ext = (h->cycle - 1) * h->spt;
+            const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
+            const long tiles = (long)((h->d.width + FIB_CUSTOM_TX - 1) / FIB_CUSTOM_TX) *
+                               ((rows + FIB_CUSTOM_TY - 1) / FIB_CUSTOM_TY);
+            prefK = tiles <= 512 ? FIB_CUSTOM_K : FIB_CUSTOM_K2;
+        }
 #endif
+        if (h->d.model == FIBHIP_BR) {
+            // up to two tiles per CU: the tick is launch/latency-bound, so all 5 sub-steps in one launch;
+            // large grids are bound by the transcendental pipe, where the redundant rim costs more than launches
+            const int ext = (h->cycle - 1) * h->spt;
+            const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
+            const long tiles = (long)((h->d.width + 53) / 54) * ((rows + 20) / 21);
+            if (tiles <= 512 && h->spt == 5) {
+                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -2;      // measured: profiles/r01_sweep_br512.txt
+                nwant = 1;
+            }
+        }
         if (h->d.model == FIBHIP_FENTON4V) {
             // rows of the largest launch: the first tick of an exchange cycle also advances the ghost rows
             const int ext = (h->cycle - 1) * h->spt;
@@ -838,7 +867,7 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
         return run_pointwise_mode(h, fn);
     }
 #endif
-#ifndef FIB_CUSTOM_ONLY
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
     if (h->d.model == FIBHIP_COURT && mode == Courtemanche::MODE_SLOW) {
         if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
         return run_pointwise_mode(h, fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>

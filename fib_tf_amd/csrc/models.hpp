@@ -56,6 +56,8 @@ template <int R> FIB_DEV vf<R> vsel(const vm<R> &m, const vf<R> &a, const vf<R> 
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = m.v[r] ? a.v[r] : b.v[r]; return o; }
 template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, float b, const vf<R> &c)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b, c.v[r]); return o; }
+template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, const vf<R> &b, const vf<R> &c)
+{ vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b.v[r], c.v[r]); return o; }
 template <int R> FIB_DEV vf<R> vfma(const vf<R> &a, float b, float c)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = __builtin_fmaf(a.v[r], b, c); return o; }
 template <int R, class F> FIB_DEV vf<R> vmap(const vf<R> &a, F f)
@@ -114,6 +116,7 @@ struct Exact {
     // a*b + c: the reference rounds the product and the sum separately
     template <class T, class B, class C>
     static FIB_DEV auto mad(const T &a, const B &b, const C &c) { return a * b + c; }
+    template <class T> static FIB_DEV T mad3(const T &a, const T &b, const T &c) { return a * b + c; }
     template <class T>
     static FIB_DEV T divc(const T &a, float c, float rc)
     {
@@ -146,6 +149,7 @@ struct Fast {
     // variant then rounds identically, so fusion depth / tile shape never change a bit of the result
     template <class T, class C>
     static FIB_DEV T mad(const T &a, float b, const C &c) { return vfma(a, b, c); }
+    template <class T> static FIB_DEV T mad3(const T &a, const T &b, const T &c) { return vfma(a, b, c); }
     template <class T>
     static FIB_DEV T divc(const T &a, float, float rc) { return a * rc; }
     template <class T>
@@ -198,6 +202,10 @@ template <int R> static FIB_DEV vf<R> clipf(const vf<R> &x, float lo, float hi)
 { vf<R> o; _Pragma("unroll") for (int r = 0; r < R; ++r) o.v[r] = fminf(fmaxf(x.v[r], lo), hi); return o; }
 
 // pointwise ops of the traced-model code generator (fib_tf_amd/traced.py), over float and vf<R>
+// (1 + sign(x)) * 0.5 and (1 - sign(x)) * 0.5 for ANY finite or infinite x, subnormals included: two scalings by
+// 2^120 take every nonzero |x| past 1, the clamp does the rest (2 instructions instead of compare/select/add/mul)
+template <class T> static FIB_DEV T g_heav(const T &x) { const T y = x * 0x1p120f; return vfma_sat(y, 0x1p120f, 0.5f); }
+template <class T> static FIB_DEV T g_heav_not(const T &x) { const T y = x * 0x1p120f; return vfma_sat(y, -0x1p120f, 0.5f); }
 template <class T> static FIB_DEV T g_sign(const T &a) { return vmap(a, [](float x) { return sgnf(x); }); }
 template <class T> static FIB_DEV T g_abs(const T &a) { return vmap(a, [](float x) { return fabsf(x); }); }
 template <class A, class B> static FIB_DEV auto g_max(const A &a, const B &b)
@@ -219,7 +227,7 @@ template <class T> static FIB_DEV T heav_not(const T &x) { return vfma_sat(x, -1
 template <class P, class T>
 static FIB_DEV T rush_larsen(const T &g, const T &ginf, const T &tau, float mdt)
 {
-    return clipf(g + (g - ginf) * P::expm1(P::div(mdt, tau)), 0.00001f, 0.99999f);
+    return clipf(P::mad3(g - ginf, P::expm1(P::div(mdt, tau)), g), 0.00001f, 0.99999f);
 }
 // tau is a Python constant: expm1(float(-dt/tau)) is formed once on the host
 static FIB_DEV float rush_larsen_c(float g, float ginf, float em1)
@@ -286,6 +294,9 @@ struct Fenton {
 // =====================================================================================
 // Beeler-Reuter  (br.py:125-332)
 // =====================================================================================
+#ifdef FIB_BR_TABLE_INC
+#include FIB_BR_TABLE_INC       // static constexpr float FIB_BR_CHEB[108]: fib_tf_amd/br.py's table, baked
+#endif
 struct BeelerReuter {
     static constexpr int NVAR = 8;                // V C M H J D F XI, br.py:87-94
     static constexpr int DEFAULT_STEPS = 5;       // br.py:98-107
@@ -316,15 +327,15 @@ struct BeelerReuter {
         inf = P::div(a, a + b);
         tau = P::div(1.0f, a + b);
     }
-    // expand_chebyshev device part, br.py:329-331:  r = d0; r += d_i * S_i  (i ascending)
-    // (P unused: the degree-8 sums keep the reference's rounding points under both policies — they
-    // amplify an ulp by ~1e2)
+    // expand_chebyshev device part, br.py:329-331:  r = d0; r += d_i * S_i  (i ascending).
+    // P::mad: product and sum rounded separately under Exact (the reference's rounding points), one fused
+    // multiply-add per term under Fast
     template <class P, class T>
     static FIB_DEV T cheb(const float *d, const T (&S)[9])
     {
-        T r = d[0] + d[1] * S[1];
+        T r = P::mad(S[1], d[1], d[0]);
 #pragma unroll
-        for (int i = 2; i <= 8; ++i) r = r + d[i] * S[i];
+        for (int i = 2; i <= 8; ++i) r = P::mad(S[i], d[i], r);
         return r;
     }
 

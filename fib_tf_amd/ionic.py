@@ -55,6 +55,7 @@ class IonicModel:
         self.dt_per_step = 1
         self.cl_observer = None
         self._stepper = None
+        self._library = None            # a specialised build of libfibhip (None = the stock library)
         # config['fast_math'] (default True): hardware exp/log/rcp/sqrt and reciprocal-multiply for the
         # model constants; False selects the rounding-faithful policy (IEEE-equivalent division, ocml
         # expf/tanhf/expm1f/logf): one float32 rounding per reference op.  Both are parity-tested; the
@@ -224,10 +225,10 @@ class IonicModel:
             st = ShardedStepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
                                 device=self.device, steps_per_tick=steps_per_tick,
                                 engine_factory=getattr(self, 'engine_factory', None),
-                                halo_ticks=getattr(self, 'halo_ticks', 4))
+                                halo_ticks=getattr(self, 'halo_ticks', 4), library=self._library)
         else:
             st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
-                              device=self.device, steps_per_tick=steps_per_tick)
+                              device=self.device, steps_per_tick=steps_per_tick, library=self._library)
         self._configure_stepper(st)
         if self.phase is not None:
             st.set_phase(self.phase)

@@ -365,6 +365,69 @@ class _Emitter:
     def __init__(self, level, remap, pot, counter):
         self.lv, self.remap, self.pot = level, remap, pot
         self.names, self.lines, self.n = {}, [], counter
+        # how many times each node is consumed: a multiply may only melt into P::mad if nothing else reads it
+        self.uses = {}
+        seen = set()
+
+        def visit(n):
+            for a in n.args:
+                if isinstance(a, Tensor):
+                    self.uses[id(a)] = self.uses.get(id(a), 0) + 1
+        for e in level.outs.values():
+            if isinstance(e, Tensor):
+                self.uses[id(e)] = self.uses.get(id(e), 0) + 1
+                _walk(e, seen, visit)
+
+    # ---- peepholes: forms that are the SAME float32 function under the rounding-faithful policy and cheaper
+    # ---- (or fusable) under the fast one -------------------------------------------------------------------
+    def _single(self, x, op):
+        return isinstance(x, Tensor) and x.op == op and self.uses.get(id(x), 0) == 1 and id(x) not in self.names
+
+    def _heaviside(self, node):
+        """(1 +- sign(x)) * 0.5  ->  g_heav / g_heav_not (fenton.py:73-79)"""
+        if node.op != 'mul':
+            return None
+        a, b = node.args
+        if not isinstance(a, Tensor):
+            a, b = b, a
+        if isinstance(b, Tensor) or b != 0.5 or not isinstance(a, Tensor) or a.op not in ('add', 'sub'):
+            return None
+        if self.uses.get(id(a), 0) != 1 or id(a) in self.names:
+            return None
+        p, q = a.args
+        if a.op == 'add' and not isinstance(p, Tensor):
+            p, q = q, p
+        if a.op == 'add' and self._single(p, 'sign') and not isinstance(q, Tensor) and q == 1.0:
+            return 'g_heav(%s)' % self.ref(p.args[0])
+        if a.op == 'sub' and not isinstance(p, Tensor) and p == 1.0 and self._single(q, 'sign'):
+            return 'g_heav_not(%s)' % self.ref(q.args[0])
+        return None
+
+    def _fused(self, node):
+        """x*y + z, z - x*y, x*y - z with a multiply nobody else reads -> P::mad / P::mad3;  1 + tanh(x)"""
+        op = node.op
+        a, b = node.args
+        if op == 'add':
+            for t, o in ((a, b), (b, a)):
+                if self._single(t, 'tanh') and not isinstance(o, Tensor) and o == 1.0:
+                    return 'P::one_plus_tanh(%s)' % self.ref(t.args[0])
+        cands = [(a, b, False, False), (b, a, False, False)] if op == 'add' else \
+                [(b, a, True, False), (a, b, False, True)]          # z - x*y ;  x*y - z
+        for m, z, neg_m, neg_z in cands:
+            if not self._single(m, 'mul'):
+                continue
+            x, y = m.args
+            if not isinstance(x, Tensor):
+                x, y = y, x
+            zs = self.ref(z)
+            if neg_z:
+                zs = '-%s' % zs if isinstance(z, Tensor) else _lit(-z)
+            if not isinstance(y, Tensor):
+                return 'P::mad(%s, %s, %s)' % (self.ref(x), _lit(-y if neg_m else y), zs)
+            if isinstance(z, Tensor):
+                xs = self.ref(x)
+                return 'P::mad3(%s, %s, %s)' % ('-%s' % xs if neg_m else xs, self.ref(y), zs)
+        return None
 
     def new(self, prefix='t'):
         self.n[0] += 1
@@ -394,7 +457,8 @@ class _Emitter:
         elif op == 'lap':
             r = 'lap'
         elif op in _BINOPS:
-            r = self.stmt('%s %s %s' % (self.ref(a[0]), _BINOPS[op], self.ref(a[1])))
+            special = self._heaviside(node) if op == 'mul' else self._fused(node)
+            r = self.stmt(special if special else '%s %s %s' % (self.ref(a[0]), _BINOPS[op], self.ref(a[1])))
         elif op == 'div':
             if not isinstance(a[1], Tensor):
                 r = self.stmt('P::divk(%s, %s)' % (self.ref(a[0]), _lit(a[1])))
@@ -445,6 +509,22 @@ class _Emitter:
         return name
 
 
+_HEAVY = frozenset(('tanh', 'exp', 'expm1', 'log', 'sqrt', 'div', 'reciprocal', 'pow'))
+
+
+def _weight(level):
+    """rough instruction count of one sub-step: graph nodes, transcendental / division nodes counted 4x"""
+    total = [0]
+
+    def visit(node):
+        if node.op not in ('param', 'var', 'bnd', 'lap'):
+            total[0] += 4 if node.op in _HEAVY else 1
+    seen = set()
+    for e in level.outs.values():
+        _walk(e, seen, visit)
+    return total[0]
+
+
 def generate(programs, nslots, remap, spt):
     """programs[mode] -> text of the generated header"""
     pot = 0
@@ -456,11 +536,25 @@ def generate(programs, nslots, remap, spt):
     TX, TY = 64 - 2 * K, 16 * R - 2 * K
     if fuse and (TX < 16 or TY < 6):
         fuse = False
+    # Small grids are launch/latency-bound: the whole tick in one launch.  Large grids are throughput-bound, where
+    # the redundant rim of a deep fusion costs more than launches: a cheap model keeps a shallow
+    # fusion (K2 <= 5), a heavy one goes back to one sub-step per launch.  "cheap" = few graph nodes per sub-step.
+    weight = max(_weight(lv) for lv in tick.levels)
+    K2 = 1
+    if fuse and weight < 250:
+        K2 = max(d for d in range(1, 6) if K % d == 0)
+    R2 = 4 if n <= 5 else 2
+    TX2, TY2 = 64 - 2 * K2, 8 * R2 - 2 * K2
     out = ['// generated by fib_tf_amd/traced.py from a traced model graph — do not edit',
+           '// graph weight per sub-step: %d' % weight,
            '#define FIB_CUSTOM_K %d' % (K if fuse else 1),
            '#define FIB_CUSTOM_TX %d' % (TX if fuse else 64),
            '#define FIB_CUSTOM_TY %d' % (TY if fuse else 4),
            '#define FIB_CUSTOM_R %d' % R,
+           '#define FIB_CUSTOM_K2 %d' % K2,
+           '#define FIB_CUSTOM_TX2 %d' % TX2,
+           '#define FIB_CUSTOM_TY2 %d' % TY2,
+           '#define FIB_CUSTOM_R2 %d' % R2,
            'struct Custom {',
            '    static constexpr int NVAR = %d;' % n,
            '    static constexpr int DEFAULT_STEPS = %d;' % spt,

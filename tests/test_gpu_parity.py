@@ -119,7 +119,33 @@ def test_br_single_step(gpu_lib, golden, cheby, n, policy):
     for k, o in zip(names, out):
         want = f['%s1_%s_n%d' % (k, tag, n)]
         scale = {'V': 120.0, 'C': 1e-5}.get(k, 1.0)
-        assert_close(o, want, STEP_TOL[policy], 'br %s %s n=%d [%s]' % (tag, k, n, policy), scale=scale)
+        tol = STEP_TOL[policy]
+        if cheby and policy == 'fast':
+            # the fast policy evaluates the degree-8 sums with fused multiply-adds: other rounding points than the
+            # reference's, amplified ~1e2 by the sums (the h/j fits are poorly conditioned, br.py:289-301)
+            tol = 1e-4
+        assert_close(o, want, tol, 'br %s %s n=%d [%s]' % (tag, k, n, policy), scale=scale)
+
+
+@pytest.mark.parametrize('policy', POLICIES)
+@pytest.mark.parametrize('skip', [False, True])
+def test_br_specialised_build_is_bit_identical(gpu_lib, policy, skip):
+    """BeelerReuter(cheby=True) runs a build of the library with its Chebyshev table compiled in as literals
+    (fib_tf_amd/br.py specialised_library); the stock library takes the table as a kernel argument.  Same
+    arithmetic: the states must agree bit for bit, whatever the fusion depth."""
+    from fib_tf_amd.br import BeelerReuter
+    res = []
+    for spec in (True, False):
+        m = BeelerReuter(cfg(96, 80, 0.809, policy, cheby=True, skip=skip, specialise=spec, duration=4.0))
+        m.add_hole_to_phase_field(30, 40, 8)
+        m.define()
+        assert (m._library is not None) == spec
+        for _ in m.run():
+            pass
+        res.append(np.stack([m._State[k].eval() for k in m.VAR_NAMES]))
+        if spec:
+            assert '_spec' in m._library._name and m._stepper.launch_plan() == (5, 1)
+    assert np.array_equal(res[0], res[1])
 
 
 SINGULAR = [-10.0001, -10.0, 7.9, -47.13, -14.1, 3.3328, 19.9]
@@ -291,6 +317,8 @@ def test_br_trajectory_64(gpu_lib, golden, name, variant, monkeypatch, policy):
         run_to(m, t - t0, hook)
         t0 = t
         rel = 2e-5 if t <= 20 else 2e-4
+        if policy == 'fast' and bool(f['cheby']):
+            rel *= 2                                        # fused multiply-adds in the Chebyshev sums (see above)
         for k in m.VAR_NAMES:
             want = f['%s_t%d' % (k, t)]
             scale = {'V': 120.0, 'C': max(span(want), float(np.abs(want).max()))}.get(k, 1.0)   # >= 1 ulp of C
