@@ -72,7 +72,7 @@ def test_reference_fenton_file_traced(ref_modules, golden):
     assert c['spt'] == 10 and m.dt_per_step == 10 and m.VAR_NAMES == ('U', 'V', 'W', 'S')
     # ten chained solve() calls are ONE sub-step function repeated: fused 10 deep
     assert len({lv.signature() for lv in c['programs'][0][1].levels}) == 1
-    assert '#define FIB_CUSTOM_K 10' in c['source'] and 'P::tanhv' in c['source'] and 'vsel(' in c['source']
+    assert '#define FIB_CUSTOM_K 10' in c['source'] and ('P::tanhv' in c['source'] or 'P::one_plus_tanh' in c['source']) and 'vsel(' in c['source']
     it = Interpreter(c, m.phase)
     st = state_of(f, m.VAR_NAMES)
     assert np.array_equal(st, np.stack([v.init for v in c['slots']]))      # define()'s own S1 initial state
