@@ -191,7 +191,7 @@ def bench_single(args):
                    'parallelism': 'single device'},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                     'kernel': '%s<%s, K=%d>' % ('strip_kernel' if fused > 1 and args.model == 'fenton' else 'tick_kernel', args.model, fused), 'us_per_launch': round(us_per_launch, 3),
+                     'kernel': '%s<%s, K=%d>' % ('strip_kernel' if fused > 1 and args.model in ('fenton', 'br') else 'tick_kernel', args.model, fused), 'us_per_launch': round(us_per_launch, 3),
                      'algorithmic_bytes_per_launch': int(abytes * cells * fused),
                      'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
                              'one-step-per-pass implementation must move, K fused sub-steps move them once'},
