@@ -28,15 +28,21 @@ def run_case(rank, world, port, case, outdir):
             cfg['engine_factory'] = OracleEngine         # CPU rehearsal; otherwise the HIP engine on device 0
         else:
             cfg['device'] = 0
-        cls = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']]
-        m = cls(cfg)
-        m.add_hole_to_phase_field(*case['hole'])
+        slow_trend = case['model'] in ('court', 'gated')
+        if case['model'] in ('ap', 'ms', 'gated', 'mrfhn'):       # traced model files (tests/models/)
+            from traced_cases import make_model
+            extra = {k: cfg[k] for k in ('halo_ticks', 'device', 'engine_factory') if k in cfg}
+            m = make_model(case['model'], H, W, case['hole'], **extra)
+        else:
+            cls = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']]
+            m = cls(cfg)
+            m.add_hole_to_phase_field(*case['hole'])
         m.define()
         m.add_pace_op('s2', 'luq', case['amp'])
         m.duration = ticks * m.dt_per_step * m.dt + 1e-9
         trend = []
         for i in m.run():
-            if case['model'] == 'court' and i % 10 == 0:
+            if slow_trend and i % 10 == 0:
                 m.fire_op('slow')
                 m.fire_op('trend')
                 trend.append(m._Trend.eval())

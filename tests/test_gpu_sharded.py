@@ -30,6 +30,11 @@ CASES = [
          'cheby': True, 'skip': True, 'halo_ticks': 2}),
     (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 23, 's2': 12, 'amp': 10.0,
          'halo_ticks': 1}),
+    # traced model files (tests/models/): the generated library behind the same row-block driver
+    (2, {'model': 'ap', 'H': 128, 'W': 80, 'diff': 1.0, 'hole': (30, 60, 8), 'ticks': 11, 's2': 4, 'amp': 1.0}),
+    (3, {'model': 'gated', 'H': 90, 'W': 64, 'diff': 2.0, 'hole': (30, 40, 6), 'ticks': 31, 's2': 14, 'amp': 10.0,
+         'halo_ticks': 2}),
+    (2, {'model': 'mrfhn', 'H': 100, 'W': 70, 'diff': 1.0, 'hole': (30, 50, 7), 'ticks': 9, 's2': 3, 'amp': 1.5}),
 ]
 
 
@@ -39,14 +44,18 @@ def single(case):
     from fib_tf_amd.court import Courtemanche
     cfg = {'height': case['H'], 'width': case['W'], 'dt': 0.1, 'dt_per_plot': 10, 'diff': case['diff'],
            'duration': 1000, 'cheby': case.get('cheby', False), 'skip': case.get('skip', False)}
-    m = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']](cfg)
-    m.add_hole_to_phase_field(*case['hole'])
+    if case['model'] in ('ap', 'ms', 'gated', 'mrfhn'):
+        from traced_cases import make_model
+        m = make_model(case['model'], case['H'], case['W'], case['hole'])
+    else:
+        m = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']](cfg)
+        m.add_hole_to_phase_field(*case['hole'])
     m.define()
     m.add_pace_op('s2', 'luq', case['amp'])
     m.duration = case['ticks'] * m.dt_per_step * m.dt + 1e-9
     trend = []
     for i in m.run():
-        if case['model'] == 'court' and i % 10 == 0:
+        if case['model'] in ('court', 'gated') and i % 10 == 0:
             m.fire_op('slow')
             m.fire_op('trend')
             trend.append(m._Trend.eval())
@@ -68,5 +77,5 @@ def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split,
     want, trend = single(case)
     out = launch(world, dict(case, engine='hip'), tmp_path)
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
-    if case['model'] == 'court':
+    if case['model'] in ('court', 'gated'):
         assert np.array_equal(out['trend'], trend)
