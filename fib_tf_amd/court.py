@@ -7,7 +7,7 @@ post-fast state and assigns the other 17 variables with 10·dt (court.py:103,118
 import numpy as np
 
 from . import _lib
-from .ionic import IonicModel, StateVar
+from .ionic import IonicModel
 
 # insertion order of court.py:57-78 == variable index in the slab
 INITIAL = (('V', -81.18), ('_Na_i_', 1.117e+01), ('_m_', 2.98e-3), ('_h_', 9.649e-1), ('_j_', 9.775e-1),

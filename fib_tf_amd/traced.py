@@ -257,7 +257,7 @@ class Compiler:
         if len(set(slot_of_param.values())) != len(slot_of_param):
             raise TraceError('solve(state): the same variable appears twice in the state')
         levels = []
-        prev_call, prev_out_slot = None, None               # output index of prev call -> slot it lands in
+        prev_out_slot = None                                # output index of the previous call -> slot it lands in
         for ci, c in enumerate(calls):
             bind = {}
             if ci == 0:
@@ -295,7 +295,7 @@ class Compiler:
             for e in outs.values():
                 self._register_vars(e)
             levels.append(Level(c.fn, bind, outs))
-            prev_call, prev_out_slot = c, out_slot
+            prev_out_slot = out_slot
         mask = set(levels[-1].outs)
         if len(levels) > 1:
             carried = set()

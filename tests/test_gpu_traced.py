@@ -114,3 +114,90 @@ def test_traced_model_errors_are_loud(gpu_lib):
         bool(tf.Variable(np.zeros((4, 4))) > 0)
     with pytest.raises(NotImplementedError, match='IonicModel.enforce_boundary'):
         tf.pad(None, None)
+
+
+def _random_model(seed, H=24, W=40):
+    """a model whose solve() is a seeded random expression over the whole op list of fib_tf_amd.tfgraph (arguments
+    kept inside every op's well-conditioned domain), three variables, three chained sub-steps"""
+    import fib_tf_amd.tfgraph as tf
+    from fib_tf_amd.traced import IonicModel
+    rng = np.random.default_rng(seed)
+
+    def expr(pool, depth):
+        if depth == 0 or rng.random() < 0.15:
+            return pool[rng.integers(len(pool))] if rng.random() < 0.8 else float(np.round(rng.uniform(-2, 2), 3))
+        k = rng.integers(16)
+        a, b = expr(pool, depth - 1), expr(pool, depth - 1)
+        if not isinstance(a, tf.Tensor):
+            a = pool[rng.integers(len(pool))]
+        if k == 0: return a + b
+        if k == 1: return a - b
+        if k == 2: return a * b
+        if k == 3: return a / (tf.abs(b) + 1.5) if isinstance(b, tf.Tensor) else a / (abs(b) + 1.5)
+        if k == 4: return tf.tanh(a)
+        if k == 5: return tf.exp(tf.clip_by_value(a, -3.0, 2.0))
+        if k == 6: return tf.log(tf.abs(a) + 1.0)
+        if k == 7: return tf.sqrt(tf.abs(a) + 0.25)
+        if k == 8: return tf.where(a > b, a * 0.5, b) if isinstance(b, tf.Tensor) else tf.where(a > b, a * 0.5, 1.0 - a)
+        if k == 9: return (1 + tf.sign(a - 0.1)) * 0.5
+        if k == 10: return tf.maximum(a, b)
+        if k == 11: return tf.minimum(a, 0.75)
+        if k == 12: return tf.pow(a, 3) * 0.1
+        if k == 13: return tf.reciprocal(tf.square(a) + 1.0)
+        if k == 14: return tf.expm1(tf.clip_by_value(a, -2.0, 0.5) * (0.01 if rng.random() < 0.5 else 1.0))
+        return -a
+
+    class Random(IonicModel):
+        def __init__(self, props):
+            IonicModel.__init__(self, props)
+            self.min_v, self.max_v, self.depol = -1.0, 1.0, 0.0
+
+        def solve(self, state):
+            u, v, w = state
+            u0 = self.enforce_boundary(u)
+            pool = [u, v, w, u0]
+            du, dv, dw = (expr(pool, 6) for _ in range(3))
+            u1 = tf.clip_by_value(u0 + self.dt * du + self.diff * self.dt * self.laplace(u0), -2.0, 2.0)
+            v1 = tf.clip_by_value(v + self.dt * dv, -2.0, 2.0)
+            w1 = self.rush_larsen(w, tf.reciprocal(1.0 + tf.exp(-u0)), 0.5 + tf.square(dw) * 0.1, self.dt)
+            return u1, v1, w1
+
+        def define(self):
+            super().define()
+            r = np.random.default_rng(seed + 1000)
+            init = [r.uniform(-1, 1, (self.height, self.width)).astype(np.float32) for _ in range(3)]
+            init[2] = np.abs(init[2])
+            U, V, Wv = (tf.Variable(a, name=n) for a, n in zip(init, 'uvw'))
+            st = (U, V, Wv)
+            for _ in range(3):
+                st = self.solve(st)
+            self.dt_per_step = 3
+            self._ode_op = tf.group(U.assign(st[0]), V.assign(st[1]), Wv.assign(st[2]))
+
+    m = Random({'height': H, 'width': W, 'dt': 0.05, 'diff': 0.8, 'dt_per_plot': 1, 'duration': 1000})
+    m.add_hole_to_phase_field(W // 2, H // 2, 5)
+    return m
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_random_expression_graphs(gpu_lib, seed):
+    """code-generator fuzz: random graphs over every supported op, GPU (rounding-faithful policy) against the
+    op-by-op interpreter; the solve() body consumes the RNG identically on every trace, so two instances of the same
+    seed build the same graph"""
+    from oracle.graph_eval import Interpreter
+    m = _random_model(seed)
+    m.define()
+    m.fast_math = False
+    ref = _random_model(seed)
+    ref.define()
+    assert m.generated_source() == ref.generated_source()
+    c = ref._analyze()
+    want = Interpreter(c, ref.phase).tick(np.stack([v.init for v in c['slots']]), 4)
+    m.duration = 4 * m.dt_per_step * m.dt + 1e-9
+    for _ in m.run():
+        pass
+    got = np.stack([m._State[n].eval() for n in m.VAR_NAMES])
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    for i, n in enumerate(m.VAR_NAMES):
+        err = float(np.abs(got[i] - want[i]).max())
+        assert err <= 3e-5, 'seed %d %s: max|d| %.3e' % (seed, n, err)

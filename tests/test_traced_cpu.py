@@ -135,3 +135,97 @@ def test_reference_court_file_traced(ref_modules, golden):
     # the Trend probe (court.py:107-111) is a host-side op with two element assigns
     mode, host = c['modes'][id(m._ops['trend'])]
     assert mode is None and len(host) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (2) no reference tree needed: tfgraph semantics, tracer structure and error behaviour on tests/models/
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def clean_modules():
+    saved = {k: sys.modules.get(k) for k in ('tensorflow', 'ionic', 'screen')}
+    yield
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def test_tfgraph_scalar_semantics():
+    """a Python / NumPy scalar becomes float32 where it meets a tensor (TF's conversion rule); Python-side products
+    stay double; NumPy scalars on the left defer to the tensor's reflected operator"""
+    import fib_tf_amd.tfgraph as tf
+    x = tf.Variable(np.zeros((4, 4)))
+    e = 0.1 * x
+    assert e.op == 'mul' and e.args[0] == float(np.float32(0.1)) and e.args[1] is x
+    e = np.float64(1.5) * 0.1 - x                     # the product is formed in double first (fenton.py:103)
+    assert e.op == 'sub' and e.args[0] == float(np.float32(1.5 * 0.1))
+    assert (np.float64(2.0) / x).op == 'div' and (x ** 2).op == 'pow' and (-x).op == 'neg'
+    assert tf.square(0.0337) == float(np.square(np.float32(0.0337)))            # court.py:310
+    assert (x > 0.5).is_mask and tf.where(x > 0.5, x, 0.0).op == 'where'
+    with pytest.raises(TypeError):
+        x + np.zeros((4, 4))                          # array constants belong in a tf.Variable
+    with pytest.raises(TypeError):
+        tf.where(x, x, x)                             # condition must be a comparison
+    g = tf.group(x.assign(x + 1), tf.group(tf.assign(x, x * 2)), None)
+    assert len(g) == 2
+    assert np.array_equal(x.eval(), np.zeros((4, 4), np.float32))               # before compile: the initial value
+
+
+@pytest.mark.parametrize('name,spt,kinds', [('ap', 10, 1), ('ms', 5, 1), ('gated', 1, 1), ('mrfhn', 4, 2)])
+def test_test_models_trace_and_interpret(clean_modules, name, spt, kinds):
+    sys.path.insert(0, HERE)
+    from traced_cases import interpret, make_model
+    m = make_model(name, 24, 32, (16, 12, 4))
+    m.define()
+    c = m._analyze()
+    assert c['spt'] == spt == m.dt_per_step
+    assert len({lv.signature() for lv in c['programs'][0][1].levels}) == kinds
+    src = m.generated_source()
+    assert src.count('struct Custom') == 1 and ('#define FIB_CUSTOM_K %d' % spt) in src
+    assert m.VAR_NAMES[0] in ('u', 'v', 'V')               # the diffusing variable is slab entry 0
+    st, trend = interpret(m, name, 12, 5)
+    assert np.isfinite(st).all() and st.shape == (len(m.VAR_NAMES), 24, 32)
+    if name == 'gated':
+        assert [n for n, _ in c['programs']] == ['_ode_op', 'slow'] and trend.shape == (2, 2)
+        assert 'MODE == 1' in src
+
+
+def test_tracer_refuses_what_it_cannot_compile(clean_modules):
+    import fib_tf_amd.tfgraph as tf
+    from fib_tf_amd.traced import IonicModel, TraceError
+    cfg0 = {'height': 16, 'width': 16, 'dt': 0.1, 'diff': 1.0, 'duration': 1, 'dt_per_plot': 1}
+    z = np.zeros([16, 16], np.float32)
+
+    def model(solve, n=1, post=None):
+        class M(IonicModel):
+            def define(self):
+                super().define()
+                vs = tuple(tf.Variable(z) for _ in range(n))
+                out = self.solve(vs)
+                if post:
+                    out = post(out)
+                self._ode_op = tf.group(*[v.assign(o) for v, o in zip(vs, out)])
+        M.solve = solve
+        m = M(dict(cfg0))
+        m.define()
+        return m
+
+    with pytest.raises(TraceError, match='enforce_boundary'):
+        model(lambda self, s: (s[0] + self.laplace(s[0]),)).generated_source()
+    with pytest.raises(TraceError, match='only one variable may diffuse'):
+        model(lambda self, s: (s[0] + self.laplace(self.enforce_boundary(s[0])),
+                               s[1] + self.laplace(self.enforce_boundary(s[1]))), n=2).generated_source()
+    with pytest.raises(TraceError, match='outside solve'):
+        model(lambda self, s: (s[0] * 2.0,), post=lambda o: (o[0] + 1.0,)).generated_source()
+    with pytest.raises(NotImplementedError, match='IonicModel.enforce_boundary'):
+        tf.pad(None, None)
+    m = model(lambda self, s: (s[0] * 2.0,))
+    m._ode_op = None
+    with pytest.raises(TraceError, match='_ode_op'):
+        m.generated_source()
+    # dt_per_step must agree with the chain define() built
+    m = model(lambda self, s: (s[0] * 2.0,))
+    m.dt_per_step = 7
+    with pytest.raises(TraceError, match='dt_per_step'):
+        m.generated_source()
