@@ -200,6 +200,7 @@ static const Variant g_variants[] = {
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 4, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
+    V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FASTSLOW, 1, 64, 4, 256),
     // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
     V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
 #endif
@@ -244,6 +245,8 @@ struct fibhip_ctx {
     long launches;
     int own0, own1;         // owned local rows
     bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
+    bool pending;           // fibhip_step's last tick has not been launched yet (see lazy_fusable)
+    launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
                             // cpos = ticks done since the last exchange
     float *probe_host;      // pinned
@@ -299,12 +302,13 @@ extern "C" int fibhip_device_count(void)
     return n;
 }
 
-static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /*TX,TY,NT or null*/)
+static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /*TX,TY,NT or null*/, int mode = -1)
 {
     const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
+    if (mode < 0) mode = h->mode;
     for (int i = 0; i < g_nvariants; ++i) {
         const Variant &v = g_variants[i];
-        if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase || v.K != K) continue;
+        if (v.model != h->d.model || v.mode != mode || v.fast != fast || v.phase != phase || v.K != K) continue;
         if (want && (v.TX != want[0] || v.TY != want[1] || v.NT != want[2])) continue;
         return &v;
     }
@@ -392,6 +396,19 @@ static int build_plan(fibhip_ctx *h)
         h->plan.push_back({best->K, best->fn, best->TY, best->TX});
         rem -= best->K;
     }
+    // Courtemanche: the reference's driver fires 'slow' right after every 10th tick (court.py:612-617).  When the
+    // last tick of a fibhip_step call is still pending at that moment, both run as ONE launch (MODE_FASTSLOW): the
+    // 21 arrays are read once instead of twice.  Requirements: a single K=1 launch per tick, no ghost rows, and
+    // every border cell's inward neighbour inside the border cell's own tile.
+    h->fused_fn = nullptr;
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    if (h->d.model == FIBHIP_COURT && h->mode == Courtemanche::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 &&
+        !h->d.ghost_top && !h->d.ghost_bottom && !getenv("FIBHIP_NO_LAZY")) {
+        const int want1[3] = {h->plan[0].TX, h->plan[0].TY, 256};
+        const Variant *v = find_variant(h, 1, want1, Courtemanche::MODE_FASTSLOW);
+        if (v && (h->d.height - 1) % v->TY != 0 && (h->d.width - 1) % v->TX != 0) h->fused_fn = v->fn;
+    }
+#endif
     return 0;
 }
 
@@ -520,6 +537,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     for (int v = 0; v < FIB_MAXVAR; ++v) h->cur[v] = h->nxt[v] = 0;
     h->phase_of_tick = 0;
     h->launches = 0;
+    h->pending = false;
+    h->fused_fn = nullptr;
     return build_plan(h);
 }
 
@@ -569,9 +588,18 @@ static Geo base_geo(const fibhip_ctx *h)
         HIPCHK(hipSetDevice((h)->d.device));                     \
     } while (0)
 
+// launches the tick fibhip_step may have left pending (defined with fibhip_step); every entry point that observes
+// or changes the state starts with it
+static int flush(fibhip_t h);
+#define FLUSH(h)                                                                                   \
+    do {                                                                                           \
+        if (int rc_ = flush(h)) return rc_;                                                        \
+    } while (0)
+
 extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
 {
     NEED(h);
+    FLUSH(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_phase inside an open tick");
     if (!phi) {
         h->has_phase = false;
@@ -590,6 +618,7 @@ extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
 extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
 {
     NEED(h);
+    FLUSH(h);
     if (!src || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "set_state: bad var %d", var);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_state inside an open tick");
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
@@ -608,6 +637,7 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
 extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
 {
     NEED(h);
+    FLUSH(h);
     if (!dst || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "get_state: bad var %d", var);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
@@ -627,6 +657,7 @@ extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
 extern "C" int fibhip_set_consts(fibhip_t h, const float *tbl, int n)
 {
     NEED(h);
+    FLUSH(h);
     if (h->d.model != FIBHIP_BR || !(h->d.flags & FIBHIP_CHEBY))
         return fail(FIBHIP_EINVAL, "set_consts: only the Beeler-Reuter Chebyshev path takes a table");
     if (!tbl || n != 12 * 9) return fail(FIBHIP_EINVAL, "set_consts: expected 108 coefficients, got %d", n);
@@ -716,9 +747,8 @@ static int check_ready(fibhip_ctx *h)
     return 0;
 }
 
-extern "C" int fibhip_step_edges(fibhip_t h)
+static int edges_impl(fibhip_t h)
 {
-    NEED(h);
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step_edges: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
     int cur[FIB_MAXVAR];
@@ -759,9 +789,8 @@ extern "C" int fibhip_step_edges(fibhip_t h)
     return 0;
 }
 
-extern "C" int fibhip_step_interior(fibhip_t h)
+static int interior_impl(fibhip_t h)
 {
-    NEED(h);
     if (h->phase_of_tick != 1) return fail(FIBHIP_EINVAL, "step_interior: call step_edges first");
     if (h->whole_in_edges) {                              // step_edges already launched the whole block
         h->phase_of_tick = 2;
@@ -798,9 +827,8 @@ extern "C" int fibhip_step_interior(fibhip_t h)
     return 0;
 }
 
-extern "C" int fibhip_step_commit(fibhip_t h)
+static int commit_impl(fibhip_t h)
 {
-    NEED(h);
     if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
     if (split_tick(h, h->plan.back())) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
     memcpy(h->cur, h->nxt, sizeof h->cur);
@@ -809,14 +837,53 @@ extern "C" int fibhip_step_commit(fibhip_t h)
     return 0;
 }
 
+static int tick_now(fibhip_t h)
+{
+    if (int rc = edges_impl(h)) return rc;
+    if (int rc = interior_impl(h)) return rc;
+    return commit_impl(h);
+}
+
+// launch the tick fibhip_step left pending; every entry point that observes or changes the state calls this first
+static int flush(fibhip_t h)
+{
+    if (!h->pending) return 0;
+    h->pending = false;
+    return tick_now(h);
+}
+
+extern "C" int fibhip_step_edges(fibhip_t h)
+{
+    NEED(h);
+    FLUSH(h);
+    return edges_impl(h);
+}
+
+extern "C" int fibhip_step_interior(fibhip_t h)
+{
+    NEED(h);
+    return interior_impl(h);
+}
+
+extern "C" int fibhip_step_commit(fibhip_t h)
+{
+    NEED(h);
+    return commit_impl(h);
+}
+
 extern "C" int fibhip_step(fibhip_t h, int nticks)
 {
     NEED(h);
     if (nticks < 0) return fail(FIBHIP_EINVAL, "negative tick count");
+    FLUSH(h);
+    if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step inside an open tick");
     for (int t = 0; t < nticks; ++t) {
-        if (int rc = fibhip_step_edges(h)) return rc;
-        if (int rc = fibhip_step_interior(h)) return rc;
-        if (int rc = fibhip_step_commit(h)) return rc;
+        if (t + 1 == nticks && h->fused_fn) {             // the last tick waits for the next call: it may be a
+            if (int rc = check_ready(h)) return rc;       // step_slow, and then both are one launch
+            h->pending = true;
+            break;
+        }
+        if (int rc = tick_now(h)) return rc;
     }
     return 0;
 }
@@ -862,6 +929,7 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
     (void)fast;
 #ifdef FIB_CUSTOM_MODEL_INC
     if (h->d.model == FIBHIP_CUSTOM) {
+        FLUSH(h);
         launch_fn fn = mode >= 1 ? (fast ? custom_mode_fn<Fast, 1>(mode) : custom_mode_fn<Exact, 1>(mode)) : nullptr;
         if (!fn) return fail(FIBHIP_EINVAL, "step_mode: the traced model has no mode %d", mode);
         return run_pointwise_mode(h, fn);
@@ -870,6 +938,15 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
 #if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
     if (h->d.model == FIBHIP_COURT && mode == Courtemanche::MODE_SLOW) {
         if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
+        if (h->pending && h->fused_fn) {                  // tick + slow as one launch
+            h->pending = false;
+            const launch_fn plain = h->plan[0].fn;
+            h->plan[0].fn = h->fused_fn;
+            const int rc = tick_now(h);
+            h->plan[0].fn = plain;
+            return rc;
+        }
+        FLUSH(h);
         return run_pointwise_mode(h, fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
                                           : launch_pointwise<Courtemanche, Exact, Courtemanche::MODE_SLOW>);
     }
@@ -887,6 +964,7 @@ extern "C" int fibhip_step_slow(fibhip_t h)
 extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, float min_v)
 {
     NEED(h);
+    FLUSH(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "pace inside an open tick");
     const Geo g = base_geo(h);
     hipLaunchKernelGGL(pace_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->slab[h->cur[0]], r0, r1, c0, c1, v, min_v);   // variable 0 starts at the slab base in both layouts
@@ -898,6 +976,7 @@ extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, 
 extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
 {
     NEED(h);
+    FLUSH(h);
     if (!out || var < 0 || var >= h->nvar || row < 0 || row >= h->d.height || col < 0 || col >= h->d.width)
         return fail(FIBHIP_EINVAL, "probe: out of range");
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "probe inside an open tick");
@@ -911,6 +990,7 @@ extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
 extern "C" int fibhip_sync(fibhip_t h)
 {
     NEED(h);
+    FLUSH(h);
     HIPCHK(hipStreamSynchronize(h->s1));
     HIPCHK(hipStreamSynchronize(h->s0));
     return 0;
@@ -919,6 +999,7 @@ extern "C" int fibhip_sync(fibhip_t h)
 extern "C" int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int *launches)
 {
     NEED(h);
+    FLUSH(h);
     const long l0 = h->launches;
     HIPCHK(hipEventRecord(h->ev_t0, h->s0));
     if (int rc = fibhip_step(h, nticks)) return rc;
@@ -1003,6 +1084,7 @@ extern "C" int fibhip_court_inter(int device, int n, const float *V, int fast, f
 extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
+    FLUSH(h);
     *dev_ptr = h->slab[h->cur[var]] + (size_t)var * h->vstride;
     return h->cur[var];
 }

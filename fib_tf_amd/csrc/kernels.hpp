@@ -21,6 +21,7 @@
 //   threads, so consecutive lanes touch consecutive LDS words for all nine taps (conflict-free for
 //   any tile shape) and every lane of every wave has work.
 #pragma once
+#include <type_traits>
 #include "models.hpp"
 
 namespace fib {
@@ -97,6 +98,20 @@ static FIB_DEV int xcd_tile(int b, int ntiles)
     const int per = (ntiles + 7) >> 3;
     return (b & 7) * per + (b >> 3);
 }
+
+// does MODE ask for two evaluations in one launch (Courtemanche::MODE_FASTSLOW)?
+template <class M, class = void>
+struct TwoPass {
+    static constexpr bool of(int) { return false; }
+    static constexpr int first(int mode) { return mode; }
+    static constexpr int second(int mode) { return mode; }
+};
+template <class M>
+struct TwoPass<M, std::void_t<decltype(M::MODE_FASTSLOW)>> {
+    static constexpr bool of(int mode) { return mode == M::MODE_FASTSLOW; }
+    static constexpr int first(int mode) { return mode == M::MODE_FASTSLOW ? M::MODE_FAST : mode; }
+    static constexpr int second(int mode) { return mode == M::MODE_FASTSLOW ? M::MODE_SLOW : mode; }
+};
 
 template <class M, class P, int MODE, int K, int TX, int TY, int NT, bool PHASE>
 __global__ void __launch_bounds__(NT)
@@ -202,7 +217,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 } else if (PHASE) {
                     l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
                 }
-                M::template step<P, MODE>(s[j], C, l, kk, sub0 + st);
+                M::template step<P, TwoPass<M>::first(MODE)>(s[j], C, l, kk, sub0 + st);
             }
         }
         if (K > 1 && st + 1 < K) {
@@ -237,6 +252,28 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 }
             }
             __syncthreads();
+        }
+    }
+
+    // ---- second evaluation on the post-update state (Courtemanche's 'slow' op, court.py:612-617) ----------
+    // It sees the boundary-enforced NEW potential: a border cell reads its inward neighbour's new value, which
+    // the host guarantees to be a cell of this same tile (fibhip.hip: lazy_fusable).
+    if constexpr (TwoPass<M>::of(MODE)) {
+        static_assert(K == 1, "two-pass modes are one sub-step per launch");
+        __syncthreads();                                           // all taps of the old tile have been read
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (fl[j] & F_ACTIVE) lds[0][li[j]] = s[j][0];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            if (fl[j] & F_ACTIVE) {
+                const int cyy = li[j] / LP - 1, cxx = li[j] - (cyy + 1) * LP - 1;
+                const int ty = clampi(cy0 + cyy + g.row_off, 1, g.Hg - 2) - g.row_off;
+                const int tx = clampi(cx0 + cxx, 1, g.W - 2);
+                const float Vc = lds[0][(ty - cy0 + 1) * LP + (tx - cx0 + 1)];
+                M::template step<P, TwoPass<M>::second(MODE)>(s[j], Vc, 0.0f, kk, 0);
+            }
         }
     }
 

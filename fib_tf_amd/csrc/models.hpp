@@ -395,7 +395,9 @@ struct CourtT {
            iCa_rel, i_u, i_v, i_w, iCa_up, i_us };
     // MODE_FAST: the 4 fast_states (court.py:42,94-102); MODE_SLOW: the other 17 (court.py:103);
     // MODE_ALL: all 21 in one evaluation (court_ultra.py:107-111)
-    enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_ALL = 2 };
+    // MODE_FASTSLOW: a fast tick and the 'slow' op the driver fires right after it (court.py:612-617) in ONE launch:
+    // the kernel runs MODE_FAST, publishes the new potential through LDS, then MODE_SLOW on the post-fast state
+    enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_ALL = 2, MODE_FASTSLOW = 3 };
     static constexpr unsigned FAST_MASK = 0xFu, ALL_MASK = (1u << NVAR) - 1u;
     static constexpr unsigned mask(int mode)
     {

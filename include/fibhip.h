@@ -112,7 +112,9 @@ int fibhip_get_state(fibhip_t h, int var, float *dst);
  * (br.py:223-240).                                                                                      */
 int fibhip_set_consts(fibhip_t h, const float *tbl, int n);
 
-/* == nticks x sess.run(self._ode_op) (ionic.py:202-203).  Asynchronous.                                  */
+/* == nticks x sess.run(self._ode_op) (ionic.py:202-203).  Asynchronous.  The library may hold the LAST tick
+ * of the call back until the next call on the handle (any call launches it; fibhip_step_slow fuses with it):
+ * invisible to the caller except that work is enqueued one call later.                                     */
 int fibhip_step(fibhip_t h, int nticks);
 
 /* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and

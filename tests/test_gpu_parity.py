@@ -148,6 +148,39 @@ def test_br_specialised_build_is_bit_identical(gpu_lib, policy, skip):
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize('policy', POLICIES)
+@pytest.mark.parametrize('H,W', [(70, 66), (65, 64), (64, 65), (80, 130)])
+def test_court_fused_slow_tick_is_bit_identical(gpu_lib, policy, H, W, monkeypatch):
+    """the reference driver fires 'slow' right after every 10th tick (court.py:612-617); the library launches that
+    tick and the slow op as ONE kernel (Courtemanche::MODE_FASTSLOW) when the grid allows it ((H-1) % 4 and
+    (W-1) % 64 nonzero) — the same arithmetic on the same inputs, so the state must not change by a bit; the
+    (65, .) and (., 65) grids take the two-launch path by construction"""
+    from fib_tf_amd.court import Courtemanche
+    res = []
+    for lazy in (True, False):
+        if lazy:
+            monkeypatch.delenv('FIBHIP_NO_LAZY', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_NO_LAZY', '1')
+        m = Courtemanche(cfg(H, W, 0.809, policy, duration=4.3))
+        m.add_hole_to_phase_field(W // 2, H // 2, 6)
+        m.define()
+        m.add_pace_op('s2', 'luq', 10.0)
+        trend = []
+        for i in m.run():
+            if i % 10 == 0:
+                m.fire_op('slow')
+                m.fire_op('trend')
+                trend.append(m._Trend.eval())
+            if i == 21:
+                m.fire_op('s2')
+            if i == 33:
+                m._State['_Ca_i_'].eval()                    # a read between a tick and nothing: flushes the pending tick
+        res.append((np.stack([m._State[k].eval() for k in m.VAR_NAMES]), np.array(trend)))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 SINGULAR = [-10.0001, -10.0, 7.9, -47.13, -14.1, 3.3328, 19.9]
 
 
