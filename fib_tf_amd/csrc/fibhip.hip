@@ -364,16 +364,26 @@ static int build_plan(fibhip_ctx *h)
             const int ext = (h->cycle - 1) * h->spt;
             const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
             const int W = h->d.width;
-            const long tiles10 = (long)((W + 43) / 44) * ((rows + 24) / 25);
-            const long tiles5 = (long)((W + 53) / 54) * ((rows + 20) / 21);
-            if (tiles10 <= 512) {
-                // a K=10 tile is latency-bound (~20 us however few there are): never let the tile count spill
-                // just past one round of 256 CUs — take the taller tile instead
-                const long t28 = (long)((W + 43) / 44) * ((rows + 27) / 28);
-                const bool taller = tiles10 > 256 && t28 <= 256;
-                prefK = 10; want[0] = 44; want[1] = taller ? 28 : 25; want[2] = -3;
+            const long tx10 = (W + 43) / 44, tx5 = (W + 53) / 54;
+            const long tiles10 = tx10 * ((rows + 24) / 25), t28 = tx10 * ((rows + 27) / 28);
+            const long tiles5 = tx5 * ((rows + 20) / 21);
+            const bool sharded = h->d.ghost_top || h->d.ghost_bottom;
+            // Measured (tools/sweep_sizes.py, profiles/r01_sweep_sizes.txt): what matters is how many tiles a CU gets.
+            // K=10: 18 us with <= 1 tile per CU, ~34 us with 2; K=5 (two launches): 27 us with <= 2 per CU (R=3),
+            // 38 us with 3, then the fatter R=4 waves win.
+            if (tiles10 <= 256 || t28 <= 256) {
+                prefK = 10; want[0] = 44; want[1] = tiles10 <= 256 ? 25 : 28; want[2] = -3;
+            } else if (sharded && tiles10 <= 512) {
+                // row blocks: the launch is sized for the first tick of an exchange cycle, later ticks have fewer
+                // ghost rows to advance (measured 21.6 us per tick for 512 + 2 x 40 rows)
+                prefK = 10; want[0] = 44; want[1] = 25; want[2] = -3;
+            } else if (tiles5 <= 512) {
+                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -3;
+            } else if (tiles10 <= 512 || t28 <= 512) {
+                prefK = 10; want[0] = 44; want[1] = tiles10 <= 512 ? 25 : 28; want[2] = -3;
+            } else if (tiles5 <= 768) {
+                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -3;
             } else {
-                (void)tiles5;
                 prefK = 5; want[0] = 54; want[1] = 21; want[2] = -4;      // measured best at 1024^2 .. 4096^2
             }
             nwant = 1;
