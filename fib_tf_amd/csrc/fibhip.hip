@@ -345,7 +345,10 @@ static int build_plan(fibhip_ctx *h)
             const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
             const long tiles = (long)((h->d.width + FIB_CUSTOM_TX - 1) / FIB_CUSTOM_TX) *
                                ((rows + FIB_CUSTOM_TY - 1) / FIB_CUSTOM_TY);
-            prefK = tiles <= 512 ? FIB_CUSTOM_K : FIB_CUSTOM_K2;
+            // a cheap graph has a shallower fusion to fall back to (K2 > 1): deep fusion only while every CU has at
+            // most one tile (the measured Fenton rule); a heavy graph (K2 == 1) keeps it up to two tiles per CU
+            // (the measured Beeler-Reuter rule)
+            prefK = tiles <= (FIB_CUSTOM_K2 > 1 ? 256 : 512) ? FIB_CUSTOM_K : FIB_CUSTOM_K2;
         }
 #endif
         if (h->d.model == FIBHIP_BR) {
