@@ -1016,6 +1016,7 @@ extern "C" int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int 
     const long l0 = h->launches;
     HIPCHK(hipEventRecord(h->ev_t0, h->s0));
     if (int rc = fibhip_step(h, nticks)) return rc;
+    FLUSH(h);                                             // the timed region ends after the LAST tick's launch
     HIPCHK(hipEventRecord(h->ev_t1, h->s0));
     HIPCHK(hipEventSynchronize(h->ev_t1));
     float ms = 0.f;
