@@ -21,6 +21,7 @@ stencil as `self.laplace(self.enforce_boundary(X))`, any number of further assig
 Laplacian (`_ops['slow']`-style), element probes into small host variables (`Trend`).  Everything else raises
 NotImplementedError at define/compile time — there is no silent fallback and no CPU path."""
 import hashlib
+import json
 import math
 import os
 import re
@@ -351,6 +352,76 @@ def _lit(c):
     return '(%s)' % s if c < 0 or s.startswith('-') else s
 
 
+# ---- division by a constant --------------------------------------------------------------------------------
+# q = a*rc; r = fma(-q, c, a); fma(r, rc, q) with rc = RN(1/c) is the correctly rounded quotient for MOST constants
+# (Markstein); the hand-written models carry an exhaustive check per constant (tools/ubench/divtest.c).  For a
+# user's constants the same exhaustive check runs here, once per constant, over all 2^23 significands of `a`
+# (the exponents of a and c only shift the result); a constant that fails — or that the float64 emulation cannot
+# decide beyond doubt — keeps the true IEEE division under the rounding-faithful policy.
+_DIVC = {}
+
+
+def _divc_cache_file():
+    return os.path.join(CACHE, 'divc_checked.json')
+
+
+def _divc_load():
+    if not _DIVC:
+        try:
+            with open(_divc_cache_file()) as f:
+                _DIVC.update(json.load(f))
+        except (OSError, ValueError):
+            pass
+
+
+def divc_is_exact(c):
+    """True iff the 3-instruction form reproduces RN(a/c) for every float32 a (normal range)"""
+    c32 = np.float32(c)
+    key = c32.tobytes().hex()
+    _divc_load()
+    if key in _DIVC:
+        return _DIVC[key]
+    ok = _divc_check(abs(float(c32)))
+    _DIVC[key] = ok
+    try:
+        os.makedirs(CACHE, exist_ok=True)
+        tmp = '%s.%d.tmp' % (_divc_cache_file(), os.getpid())
+        with open(tmp, 'w') as f:
+            json.dump(_DIVC, f)
+        os.replace(tmp, _divc_cache_file())
+    except OSError:
+        pass
+    return ok
+
+
+def _divc_check(c):
+    if not np.isfinite(c) or c == 0.0:
+        return False
+    rc32 = np.float32(1.0 / c)                              # RN(1/c): double division then one rounding is safe (53 >= 2*24+2)
+    if not np.isfinite(rc32) or abs(float(rc32)) < 1.2e-38 or c < 1.2e-38:
+        return False
+    rc = float(rc32)
+    for lo in range(1 << 23, 1 << 24, 1 << 20):
+        a = np.arange(lo, lo + (1 << 20), dtype=np.float64)                # every significand, exponent 2^23
+        q = (a * rc).astype(np.float32).astype(np.float64)                  # a*rc is exact in double (48 bits)
+        r = (a - q * c).astype(np.float32).astype(np.float64)               # exact difference, then fma's one rounding
+        u = r * rc                                                          # exact (48 bits)
+        s = q + u                                                           # TwoSum: s + e == q + u exactly
+        bb = s - q
+        e = (q - (s - bb)) + (u - bb)
+        f = s.astype(np.float32)
+        f64 = f.astype(np.float64)
+        d = (s - f64) + e                                                   # exact sum minus the candidate rounding
+        half = 0.5 * np.spacing(f)                                          # float32 ulp of the candidate
+        half = np.where(np.abs(np.frexp(f64)[0]) == 0.5, 0.5 * half, half)  # below a power of two the ulp halves
+        if np.any(np.abs(d) > half * (1 - 1e-9)):                           # wrong or too close to a tie to call
+            return False
+        want = (a / c).astype(np.float32)
+        if not np.array_equal(f, want):
+            return False
+    return True
+
+
 _TEMP = re.compile(r'^t\d+$')
 _BINOPS = {'add': '+', 'sub': '-', 'mul': '*'}
 _CMP = {'gt': 'vcmp_gt', 'ge': 'vcmp_ge', 'lt': 'vcmp_lt', 'le': 'vcmp_le', 'eq': 'vcmp_eq', 'ne': 'vcmp_ne'}
@@ -461,7 +532,11 @@ class _Emitter:
             r = self.stmt(special if special else '%s %s %s' % (self.ref(a[0]), _BINOPS[op], self.ref(a[1])))
         elif op == 'div':
             if not isinstance(a[1], Tensor):
-                r = self.stmt('P::divk(%s, %s)' % (self.ref(a[0]), _lit(a[1])))
+                if divc_is_exact(a[1]):                     # x / c through RN(1/c): 3 instructions, bit-identical
+                    rc = float(np.float32(1.0) / np.float32(a[1]))
+                    r = self.stmt('P::divc(%s, %s, %s)' % (self.ref(a[0]), _lit(a[1]), _lit(rc)))
+                else:
+                    r = self.stmt('P::divk(%s, %s)' % (self.ref(a[0]), _lit(a[1])))
             else:
                 r = self.stmt('P::div(%s, %s)' % (self.ref(a[0]), self.ref(a[1])))
         elif op in _CMP:
