@@ -55,9 +55,13 @@ for case, model, mid, flags, ticks in (('fenton_d1.5', 'fenton', _lib.FENTON4V, 
     ph, init = phase(N), init_for(model)
     for fast in (1, 0):
         row = []
-        for lib, m, fl in ((_lib.load(so), _lib.CUSTOM, 0), (None, mid, flags)):
+        hand = None
+        if model == 'br':                                   # the product path: table-specialised build (fib_tf_amd/br.py)
+            from fib_tf_amd.br import specialised_library
+            hand = specialised_library(BeelerReuter({'height': 8, 'width': 8, 'cheby': True})._table32())
+        for lib, m, fl in ((_lib.load(so), _lib.CUSTOM, 0), (hand, mid, flags)):
             st = _lib.Stepper(m, N, N, meta['dt'], meta['diff'], flags=fl | (_lib.FAST if fast else 0), library=lib)
-            if model == 'br' and lib is None:
+            if model == 'br' and m == mid:
                 st.set_consts(BeelerReuter({'height': 8, 'width': 8}).chebyshev_table())
             st.set_phase(ph)
             st.set_state(-1, init)
