@@ -157,6 +157,8 @@ static const Variant g_variants[] = {
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 6),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 32, 4),
@@ -369,25 +371,27 @@ static int build_plan(fibhip_ctx *h)
             const int W = h->d.width;
             const long tx10 = (W + 43) / 44, tx5 = (W + 53) / 54;
             const long tiles10 = tx10 * ((rows + 24) / 25), t28 = tx10 * ((rows + 27) / 28);
-            const long tiles5 = tx5 * ((rows + 20) / 21);
+            const long t21 = tx5 * ((rows + 20) / 21), t23 = tx5 * ((rows + 22) / 23);
+            const long r21 = (t21 + 255) / 256, r23 = (t23 + 255) / 256;       // tiles per CU, rounded up
             const bool sharded = h->d.ghost_top || h->d.ghost_bottom;
             // Measured (tools/sweep_sizes.py, profiles/r01_sweep_sizes.txt): what matters is how many tiles a CU gets.
-            // K=10: 18 us with <= 1 tile per CU, ~34 us with 2; K=5 (two launches): 27 us with <= 2 per CU (R=3),
-            // 38 us with 3, then the fatter R=4 waves win.
+            // K=10: 18 us with <= 1 tile per CU, ~34 us with 2.  K=5 (two launches), R=3: 27 us with <= 2 per CU, 38 us
+            // with 3; the 23-row tile fills its 11 waves exactly (33 rows) and is taken when it saves a whole round
+            // of tiles.  Beyond that the fatter R=4 waves win, with the wave-exact 22-row tile.
             if (tiles10 <= 256 || t28 <= 256) {
                 prefK = 10; want[0] = 44; want[1] = tiles10 <= 256 ? 25 : 28; want[2] = -3;
             } else if (sharded && tiles10 <= 512) {
                 // row blocks: the launch is sized for the first tick of an exchange cycle, later ticks have fewer
                 // ghost rows to advance (measured 21.6 us per tick for 512 + 2 x 40 rows)
                 prefK = 10; want[0] = 44; want[1] = 25; want[2] = -3;
-            } else if (tiles5 <= 512) {
-                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -3;
+            } else if (r21 <= 2 || r23 <= 2) {
+                prefK = 5; want[0] = 54; want[1] = r21 <= 2 ? 21 : 23; want[2] = -3;
             } else if (tiles10 <= 512 || t28 <= 512) {
                 prefK = 10; want[0] = 44; want[1] = tiles10 <= 512 ? 25 : 28; want[2] = -3;
-            } else if (tiles5 <= 768) {
-                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -3;
+            } else if (r21 <= 3 || r23 <= 3) {
+                prefK = 5; want[0] = 54; want[1] = r21 <= 3 ? 21 : 23; want[2] = -3;
             } else {
-                prefK = 5; want[0] = 54; want[1] = 21; want[2] = -4;      // measured best at 1024^2 .. 4096^2
+                prefK = 5; want[0] = 54; want[1] = 22; want[2] = -4;      // measured best at 1024^2 .. 4096^2
             }
             nwant = 1;
         }

@@ -16,9 +16,10 @@ def run(model, size, variant=None, k=None):
     best = min(st.time_steps(n)[0] for _ in range(3))
     print('%-7s %5d %-14s plan %-8s %8.2f us/tick %9.0f Mcs/s' % (model, size, variant or ('K=%s'%k if k else 'default'), st.launch_plan(), best*1000/n, m.height*m.width*n*m.dt_per_step/(best*1e-3)/1e6), flush=True)
     st.close()
-for size in (384, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1536, 2048):
-    for v in (None, '10,44,28,-3', '10,44,25,-3', '5,54,21,-4', '5,54,21,-3'):
+for size in (384, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1536, 2048, 4096):
+    for v in (None, '10,44,28,-3', '10,44,25,-3', '5,54,21,-4', '5,54,22,-4', '5,54,21,-3', '5,54,23,-3'):
         run('fenton', size, v)
-for size in (576, 640, 704, 768, 896, 1024):
+for size in (512, 576, 640, 704, 768, 896, 1024):
     for k in (None, 5, 1):
         run('br', size, None, k)
+
