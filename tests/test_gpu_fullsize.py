@@ -58,6 +58,53 @@ def test_fenton_512_plan_invariance(gpu_lib, policy, monkeypatch):
         assert np.array_equal(v, out['']), 'plan %r changes the result' % k
 
 
+@pytest.mark.parametrize('size,variants', [(768, ('5,54,23,-3', '10,44,28,-3', '1,64,4,256')),
+                                           (1536, ('5,54,22,-4', '5,54,21,-3'))])
+def test_fenton_plan_invariance_other_sizes(gpu_lib, size, variants, monkeypatch):
+    """the size-dependent default plans (wave-exact 54x23 / 54x22 tiles, fibhip.hip build_plan) against other
+    shapes: bit-identical"""
+    from fib_tf_amd.fenton import Fenton4v
+    out = {}
+    for variant in ('',) + variants:
+        if variant:
+            monkeypatch.setenv('FIBHIP_VARIANT', variant)
+        else:
+            monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+        m = Fenton4v(dict(BASE, height=size, width=size, diff=1.5))
+        m.add_hole_to_phase_field(size // 2, size // 2, size // 17)
+        m.define()
+        m.add_pace_op('s2', 'luq', 1.0)
+        advance(m, 8, lambda i: m.fire_op('s2') if i == 3 else None)
+        out[variant] = state(m)
+    for k, v in out.items():
+        assert np.array_equal(v, out['']), 'plan %r changes the result at %d^2' % (k, size)
+
+
+def test_fenton_4096_config3_grid_vs_oracle(gpu_lib, orc, monkeypatch):
+    """BASELINE configs[3]'s 4096x4096 grid on ONE GPU (hole (2048,2048,240), S1): 20 sub-steps against the oracle,
+    and the default plan (5 fused sub-steps, 54x22 tiles) bit-identical to one sub-step per launch"""
+    from fib_tf_amd.fenton import Fenton4v
+    res = []
+    for k in ('', '1'):
+        if k:
+            monkeypatch.setenv('FIBHIP_K', k)
+        else:
+            monkeypatch.delenv('FIBHIP_K', raising=False)
+        m = Fenton4v(dict(BASE, height=4096, width=4096, diff=1.5))
+        m.add_hole_to_phase_field(2048, 2048, 240)
+        m.define()
+        if not k:
+            ref = state(m)
+            assert m._stepper.launch_plan() == (5, 2)
+        advance(m, 2)
+        res.append(state(m))
+        m._stepper.close()
+    assert np.array_equal(res[0], res[1])
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 20)
+    err = np.abs(res[0].astype(np.float64) - ref).max()
+    assert err <= 2e-5, err
+
+
 def test_fenton_mirror_symmetry_1024(gpu_lib):
     """a problem that is mirror-symmetric about the horizontal mid-line stays so (to round-off: the
     reference's diagonal sum is not associative under the mirror)"""
