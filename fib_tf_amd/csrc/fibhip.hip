@@ -691,10 +691,28 @@ extern "C" int fibhip_set_consts(fibhip_t h, const float *tbl, int n)
 // cells of a tile are owned (and rewritten) by a neighbouring tile.  With K == 1 the pointwise
 // variables are read and written by the same thread only, so they are updated in place — which is
 // also what lets Courtemanche's fast tick assign 4 of its 21 arrays and leave the rest untouched.
+// which variables the tick op of this handle assigns (M::mask(mode))
+static unsigned tick_mask(const fibhip_ctx *h)
+{
+    switch (h->d.model) {
+    case FIBHIP_FENTON4V: return Fenton::mask(h->mode);
+    case FIBHIP_BR: return BeelerReuter::mask(h->mode);
+    case FIBHIP_COURT: return Courtemanche::mask(h->mode);
+    case FIBHIP_COURT_US: return CourtemancheUS::mask(h->mode);
+#ifdef FIB_CUSTOM_MODEL_INC
+    case FIBHIP_CUSTOM: return Custom::mask(h->mode);
+#endif
+    default: return ~0u;
+    }
+}
+
 static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *nxt)
 {
+    const unsigned wmask = tick_mask(h);
     for (int v = 0; v < h->nvar; ++v) {
-        const bool flip = (v == 0) || (K > 1);
+        // a variable the op never assigns is read-only for the whole launch: it stays where it is (Courtemanche's
+        // fast tick: 17 of 21 arrays)
+        const bool flip = (v == 0) || (K > 1 && ((wmask >> v) & 1u));
         nxt[v] = flip ? (cur[v] ^ 1) : cur[v];
         c.in[v] = h->slab[cur[v]] + (size_t)v * h->vstride;
         c.out[v] = h->slab[nxt[v]] + (size_t)v * h->vstride;
