@@ -511,6 +511,9 @@ class _Emitter:
         return self.emit(x) if isinstance(x, Tensor) else 'T_of<T>(%s)' % _lit(x)
 
     def slot_expr(self, node):
+        if node.op == 'var' and node._slot is None:
+            raise TraceError('variable %r is not a grid array: small host variables cannot enter the cell arithmetic'
+                             % (node.name,))
         p = self.lv.bind[node.attr] if node.op == 'param' else node._slot
         return 's[%d]' % self.remap[p]                      # (generation runs before slots are renumbered)
 
