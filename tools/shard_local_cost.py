@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fib_tf_amd import _lib
 import numpy as np
 W, rows, spt = 512, 512, 10
-for m in (1, 2, 4, 6, 8):
+for m in (1, 2, 3, 4, 5, 6, 8):
     g = m * spt
     H = rows + 2 * g
     st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.5, flags=_lib.FAST | _lib.ROW_INTERLEAVED, global_height=4 * rows,
