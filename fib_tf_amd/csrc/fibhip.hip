@@ -311,6 +311,7 @@ static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /
     for (int i = 0; i < g_nvariants; ++i) {
         const Variant &v = g_variants[i];
         if (v.model != h->d.model || v.mode != mode || v.fast != fast || v.phase != phase || v.K != K) continue;
+        if ((h->d.flags & FIBHIP_ZEROPAD) && v.NT < 0) continue;   // the zero-padded Laplacian lives in tick_kernel only
         if (want && (v.TX != want[0] || v.TY != want[1] || v.NT != want[2])) continue;
         return &v;
     }
@@ -378,7 +379,12 @@ static int build_plan(fibhip_ctx *h)
             // K=10: 18 us with <= 1 tile per CU, ~34 us with 2.  K=5 (two launches), R=3: 27 us with <= 2 per CU, 38 us
             // with 3; the 23-row tile fills its 11 waves exactly (33 rows) and is taken when it saves a whole round
             // of tiles.  Beyond that the fatter R=4 waves win, with the wave-exact 22-row tile.
-            if (tiles10 <= 256 || t28 <= 256) {
+            if (h->d.flags & FIBHIP_ZEROPAD) {
+                // fenton_simple.py's Laplacian exists in the flat tick_kernel only (measured at 512^2: 10 x 32x32 x 1024
+                // threads 20.8 us per 10 steps, 5 x 32x32 x 512 25.4)
+                const long t32 = (long)((W + 31) / 32) * ((rows + 31) / 32);
+                prefK = t32 <= 512 ? 10 : 5; want[0] = 32; want[1] = 32; want[2] = t32 <= 512 ? 1024 : 512;
+            } else if (tiles10 <= 256 || t28 <= 256) {
                 prefK = 10; want[0] = 44; want[1] = tiles10 <= 256 ? 25 : 28; want[2] = -3;
             } else if (sharded && tiles10 <= 512) {
                 // row blocks: the launch is sized for the first tick of an exchange cycle, later ticks have fewer
@@ -487,6 +493,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     const int ming = (desc->ghost_top && desc->ghost_bottom)
                          ? (desc->ghost_top < desc->ghost_bottom ? desc->ghost_top : desc->ghost_bottom)
                          : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
+    if ((desc->flags & FIBHIP_ZEROPAD) && (desc->ghost_top || desc->ghost_bottom))
+        return fail(FIBHIP_EINVAL, "FIBHIP_ZEROPAD is a single-device option (no row blocks)");
     if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt)
         return fail(FIBHIP_EINVAL, "ghost width %d < steps_per_tick %d", ming, h->spt);
     h->cycle = (desc->ghost_top || desc->ghost_bottom) ? ming / h->spt : 1;
@@ -596,6 +604,7 @@ static Geo base_geo(const fibhip_ctx *h)
     g.rb0 = g.rb1 = 0;
     g.ty_a = 0;
     g.tiles_x = g.ntiles = 0;
+    g.zeropad = (h->d.flags & FIBHIP_ZEROPAD) ? 1 : 0;
     return g;
 }
 
@@ -1073,7 +1082,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
         if (phi) {
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
-            g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
+            g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0; g.zeropad = 0;
             hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
         }
         const float mdt = (float)(-dt);

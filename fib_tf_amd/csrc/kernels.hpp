@@ -37,6 +37,8 @@ struct Geo {
     int rb0, rb1;    // ... and, when ty_a < tile rows, a second band [rb0, rb1) served by the same launch
     int ty_a;        //     (the two edge strips of a row block); tile rows >= ty_a belong to the second band
     int tiles_x, ntiles;
+    int zeropad;     // FIBHIP_ZEROPAD: the Laplacian of fenton_simple.py — taps outside the grid read 0 and the nine
+                     // products are accumulated in the kernel's row-major order (tick_kernel only)
 };
 
 // tile row `by` -> first local row of the tile and the end of the band it belongs to
@@ -81,6 +83,20 @@ static FIB_DEV float stencil9(float N, float S, float Wv, float E, float NW, flo
 {
     const float l = (((N + S) + Wv) + E) + 0.5f * (((NW + SW) + NE) + SE);
     return l - 6.0f * C;
+}
+// The 3x3 convolution of fenton_simple.py:38-49 ([[.5,1,.5],[1,-6,1],[.5,1,.5]], padding SAME).  TensorFlow does
+// not specify its accumulation order; this is the kernel's row-major order, as in tests/golden/_standin.
+static FIB_DEV float stencil9_conv(float N, float S, float Wv, float E, float NW, float SW, float NE, float SE, float C)
+{
+    float a = 0.5f * NW;
+    a = a + N;
+    a = a + 0.5f * NE;
+    a = a + Wv;
+    a = a + (-6.0f * C);
+    a = a + E;
+    a = a + 0.5f * SW;
+    a = a + S;
+    return a + 0.5f * SE;
 }
 // phase-field correction, ionic.py:78-80, from the pre-differenced ϕ terms
 // (the division is always the correctly rounded form: the Laplacian incl. its phase term is pure
@@ -143,7 +159,11 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         int yy = clampi(cy0 - 1 + ly + g.row_off, 1, g.Hg - 2) - g.row_off;
         yy = clampi(yy, 0, g.H - 1);                               // stay inside this slab
         const int xx = clampi(cx0 - 1 + lx, 1, g.W - 2);
-        const float v = vin[(size_t)yy * g.pitch + xx];
+        float v = vin[(size_t)yy * g.pitch + xx];
+        if (g.zeropad) {                                           // outside the grid: 0 (conv2d padding='SAME')
+            const int gyy = cy0 - 1 + ly + g.row_off, gxx = cx0 - 1 + lx;
+            if (gyy < 0 || gyy > g.Hg - 1 || gxx < 0 || gxx > g.W - 1) v = 0.0f;
+        }
         lds[0][i] = v;
         if (K > 1) lds[K > 1 ? 1 : 0][i] = v;
         if (PHI_TILE) {                                            // ϕ is REFLECT-padded, not clamped (ionic.py:75-76)
@@ -187,10 +207,11 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
             f |= F_ACTIVE;
             if (!border) {
                 f |= F_WLDS;
-                if (gyg == 1) f |= F_TOP | (cyy >= 1 ? F_TOP2 : 0u);
-                if (gyg == g.Hg - 2) f |= F_BOT | (cyy <= CY - 2 ? F_BOT2 : 0u);
-                if (gx == 1) f |= F_LEFT | (cxx >= 1 ? F_LEFT2 : 0u);
-                if (gx == g.W - 2) f |= F_RIGHT | (cxx <= CX - 2 ? F_RIGHT2 : 0u);
+                const bool ghost = !g.zeropad;                     // the cells beyond the border stay 0 there
+                if (gyg == 1) f |= F_TOP | (cyy >= 1 && ghost ? F_TOP2 : 0u);
+                if (gyg == g.Hg - 2) f |= F_BOT | (cyy <= CY - 2 && ghost ? F_BOT2 : 0u);
+                if (gx == 1) f |= F_LEFT | (cxx >= 1 && ghost ? F_LEFT2 : 0u);
+                if (gx == g.W - 2) f |= F_RIGHT | (cxx <= CX - 2 && ghost ? F_RIGHT2 : 0u);
             }
             if (gy >= y0 && gy < min(y0 + TY, rend) && gx >= x0 && gx < x0 + TX) f |= F_STORE;
         }
@@ -210,7 +231,8 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float N = A[i - LP], S = A[i + LP], Wv = A[i - 1], E = A[i + 1];
                 const float NW = A[i - LP - 1], SW = A[i + LP - 1], NE = A[i - LP + 1], SE = A[i + LP + 1];
                 const float C = A[i];
-                float l = stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
+                float l = g.zeropad ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C)
+                                    : stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
                 if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + phase_term, IEEE division
                     const float dy = lphi[i + LP] - lphi[i - LP], dx = lphi[i + 1] - lphi[i - 1];
                     l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);

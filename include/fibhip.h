@@ -50,6 +50,8 @@ enum fibhip_flags {
                               /* looser parity tolerance, see DESIGN.md                                    */
     FIBHIP_ALLVARS = 1u << 4, /* COURT: every tick updates all 21 variables with dt (court_ultra.py:      */
                               /* 107-111,127-128) instead of the fast/slow split                           */
+    FIBHIP_ZEROPAD = 1u << 6, /* Laplacian of fenton_simple.py / fenton_jit.py: a 3x3 convolution with zero padding        */
+                              /* (fenton_simple.py:38-49) instead of IonicModel.laplace; single device only              */
     FIBHIP_ROW_INTERLEAVED = 1u << 5 /* device slab layout [height][nvar][width] instead of               */
                               /* [nvar][height][width]: the rows a row block exchanges with a neighbour    */
                               /* (all arrays) are then ONE contiguous block.  Host-side get/set_state keep  */

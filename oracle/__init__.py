@@ -63,6 +63,8 @@ def lib():
             'orc_court_ultra_run': [i, i, d, d, _fp, i, _fp, _fp, i],
             'orc_court_ultra_us_run': [i, i, d, d, _fp, i, _fp, _fp, i],
             'orc_court_us_inter': [f, _fp, _fp],
+            'orc_laplace_zeropad': [i, i, _fp, _fp],
+            'orc_fenton_simple_run': [i, i, d, d, _fp, _fp, i],
         }
         for name, args in sig.items():
             fn = getattr(_lib, name)
@@ -205,6 +207,15 @@ def court_us_inter(V):
         lib().orc_court_us_inter(C.c_float(v), C.byref(x), C.byref(y))
         a.ravel()[k], b.ravel()[k] = x.value, y.value
     return a, b
+
+
+def fenton_simple_run(slab, dt, diff, nsteps):
+    """fenton_simple.py's step (zero-padded convolution Laplacian), nsteps times, in place"""
+    assert slab.dtype == np.float32 and slab.flags.c_contiguous and slab.shape[0] == 4
+    _, H, W = slab.shape
+    tmp = np.empty(6 * H * W, np.float32)
+    lib().orc_fenton_simple_run(H, W, dt, diff, _p(slab), _p(tmp), nsteps)
+    return slab
 
 
 def host_cores():

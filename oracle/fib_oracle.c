@@ -611,6 +611,53 @@ void orc_court_run(int H, int W, double dt, double diff, const float *phi, int c
     }
 }
 
+/* fenton_simple.py / fenton_jit.py: the Laplacian is tf.nn.depthwise_conv2d with the 3x3 kernel
+ * [[.5,1,.5],[1,-6,1],[.5,1,.5]] and padding='SAME' (zeros outside the grid), fenton_simple.py:38-49.  TensorFlow does
+ * not specify its accumulation order: row-major over the kernel here, as tests/golden/_standin does.        */
+void orc_laplace_zeropad(int H, int W, const float *X, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+#define ZP(dr, dc) (((r + (dr)) < 0 || (r + (dr)) >= H || (c + (dc)) < 0 || (c + (dc)) >= W) ? 0.0f : X[(long)(r + (dr)) * W + (c + (dc))])
+            float a = 0.5f * ZP(-1, -1);
+            a = a + ZP(-1, 0);
+            a = a + 0.5f * ZP(-1, 1);
+            a = a + ZP(0, -1);
+            a = a + (-6.0f * ZP(0, 0));
+            a = a + ZP(0, 1);
+            a = a + 0.5f * ZP(1, -1);
+            a = a + ZP(1, 0);
+            a = a + 0.5f * ZP(1, 1);
+#undef ZP
+            out[(long)r * W + c] = a;
+        }
+}
+
+/* Fenton4vSimple.solve (fenton_simple.py:122-134) x nsteps: enforce_boundary, differentiate on the raw state, Euler
+ * update with the zero-padded Laplacian of the boundary-enforced potential.  slab [4][H][W]; tmp [4][H][W] + 2*H*W */
+void orc_fenton_simple_run(int H, int W, double dt, double diff, float *slab, float *tmp, int nsteps)
+{
+    const long n = (long)H * W;
+    float *a = slab, *b = tmp, *U0 = tmp + 4 * n, *lap = tmp + 5 * n;
+    const float dtf = F(dt), ddt = F(diff * dt);
+    for (int s = 0; s < nsteps; ++s) {
+        orc_enforce_boundary(H, W, a, U0);
+        orc_laplace_zeropad(H, W, U0, lap);
+        orc_fenton_diff(n, a, a + n, a + 2 * n, a + 3 * n, b, b + n, b + 2 * n, b + 3 * n);   /* dU dV dW dS */
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; ++i) {
+            const float dU = b[i], dV = b[n + i], dW = b[2 * n + i], dS = b[3 * n + i];
+            b[i] = (U0[i] + dtf * dU) + ddt * lap[i];                    /* fenton_simple.py:129 */
+            b[n + i] = a[n + i] + dtf * dV;
+            b[2 * n + i] = a[2 * n + i] + dtf * dW;
+            b[3 * n + i] = a[3 * n + i] + dtf * dS;
+        }
+        float *t = a; a = b; b = t;
+    }
+    if (a != slab) memcpy(slab, a, 4 * n * sizeof(float));
+}
+
 void orc_set_threads(int n)
 {
 #ifdef _OPENMP

@@ -115,7 +115,38 @@ def clip_by_value(x, lo, hi, name=None):
 
 
 def constant(v, dtype=None, name=None):
-    return np.asarray(v)                            # only used for paddings
+    a = np.asarray(v)
+    if dtype in (1, _f32, 'float32'):               # fenton_simple.py:35 passes the enum value of tf.float32
+        return Tensor(a.astype(_f32))
+    return a                                        # paddings
+
+
+def expand_dims(x, axis, name=None):
+    return Tensor(np.expand_dims(_raw(x), axis))
+
+
+class _NN:
+    """tf.nn.depthwise_conv2d for the one use the reference makes of it (fenton_simple.py:38-49): a [1,H,W,1]
+    image, a [3,3,1,1] kernel, stride 1, padding='SAME' = zero padding.  The accumulation order of TF's kernel is
+    not specified; taps are accumulated in the kernel's row-major order, one float32 rounding per multiply and
+    per add."""
+
+    @staticmethod
+    def depthwise_conv2d(x, k, strides, padding, name=None):
+        x, k = _raw(x), _raw(k)
+        assert x.ndim == 4 and x.shape[0] == 1 and x.shape[3] == 1 and k.shape == (3, 3, 1, 1)
+        assert list(strides) == [1, 1, 1, 1] and padding == 'SAME'
+        img = np.pad(x[0, :, :, 0], 1, mode='constant')
+        H, W = x.shape[1], x.shape[2]
+        acc = None
+        for a in range(3):
+            for b in range(3):
+                term = (_f32(k[a, b, 0, 0]) * img[a:a + H, b:b + W]).astype(_f32)
+                acc = term if acc is None else (acc + term).astype(_f32)
+        return Tensor(acc[None, :, :, None])
+
+
+nn = _NN()
 
 
 def pad(x, paddings, mode='CONSTANT', name=None):

@@ -39,6 +39,7 @@ import fenton                                       # noqa: E402  (reference)
 import br                                           # noqa: E402  (reference)
 import court                                        # noqa: E402  (reference)
 import court_ultra                                  # noqa: E402  (reference)
+import fenton_simple                                # noqa: E402  (reference)
 
 T = tf.Tensor
 f32 = np.float32
@@ -276,6 +277,32 @@ def fenton_traj(name, H, W, diff, hole, ticks, snaps, s2=None, cube_every=None):
     save(name, **out)
 
 
+def fenton_simple_traj(name, H, W, diff, steps, snaps, s2_step):
+    """fenton_simple.py (= fenton_jit.py without the XLA scope): one solve per op, Laplacian by a zero-padded
+    3x3 convolution (fenton_simple.py:38-49), its own S2 op `U = max(U, s2_init)` on [:H//2, :W//2] fired after
+    step int(s2_time/dt) (fenton_simple.py:150-152,172,191-192)"""
+    tf.variable_override.clear()
+    c = {'width': W, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'diff': diff, 'samples': steps,
+         's2_time': s2_step * 0.1}
+    fenton_simple.config = c                        # the constructor reads this module-level name (fenton_simple.py:71)
+    m = fenton_simple.Fenton4vSimple(c)
+    out = {'diff': diff, 'dt': 0.1, 's2_step': int(c['s2_time'] / c['dt'])}
+    for i in range(steps):
+        m.define()
+        if i == 0:
+            for var, _ in m._ode_op:
+                out['init_' + var.name] = np.array(var.a)
+        apply_pairs(m._ode_op)
+        if i == out['s2_step']:
+            m.define()
+            apply_pairs([m._s2_op])
+        if (i + 1) in snaps:
+            for k, v in current('UVWS').items():
+                out['%s_t%d' % (k, i + 1)] = v
+    out['snap_steps'] = np.array(sorted(snaps))
+    save(name, **out)
+
+
 def br_traj(name, H, W, diff, hole, ticks, snaps, cheby, skip, s2=None):
     tf.variable_override.clear()
     m = br.BeelerReuter(cfg(H, W, diff, cheby=cheby, skip=skip))
@@ -391,6 +418,9 @@ def main():
         court_ultra_traj('court_ultra_traj', 48, 56, 1.5, [(28, 24, 5), (28, 24, 22, True)], 120, {1, 10, 60, 120},
                          s2=(50, 'luq', 10.0))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'fenton_simple':
+        fenton_simple_traj('fenton_simple_traj', 40, 56, 1.5, 300, {1, 2, 10, 100, 200, 300}, 150)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'court_ultra_us':
         court_ultra_traj('court_ultra_us_traj', 40, 48, 1.5, [(24, 20, 5)], 120, {1, 10, 60, 120},
                          s2=(50, 'luq', 10.0), ultra_slow=True)
@@ -419,6 +449,7 @@ def main():
                      s2=(50, 'luq', 10.0))
     court_ultra_traj('court_ultra_us_traj', 40, 48, 1.5, [(24, 20, 5)], 120, {1, 10, 60, 120},
                      s2=(50, 'luq', 10.0), ultra_slow=True)
+    fenton_simple_traj('fenton_simple_traj', 40, 56, 1.5, 300, {1, 2, 10, 100, 200, 300}, 150)
 
 
 if __name__ == '__main__':

@@ -723,3 +723,58 @@ def test_timeline_and_save_graph_keys(gpu_lib, tmp_path):
     tr = json.load(open(name))
     ev = tr['traceEvents'][0]
     assert ev['ph'] == 'X' and ev['dur'] > 0 and 'sub-steps fused' in ev['name']
+
+
+# --------------------------------------------------------------------------------------------
+# fenton_simple.py / fenton_jit.py: the stand-alone scripts with the zero-padded convolution Laplacian
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('policy', POLICIES)
+def test_fenton_simple_trajectory(gpu_lib, golden, policy, tmp_path, capsys):
+    from fib_tf_amd.fenton_simple import Fenton4vSimple
+    f = golden('fenton_simple_traj')
+    H, W = f['init_U'].shape
+    cfg_s = {'width': W, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'diff': float(f['diff']), 'samples': 300,
+             's2_time': int(f['s2_step']) * 0.1, 'fast_math': policy == 'fast',
+             'timeline_name': str(tmp_path / 'timeline_simple.json')}
+    got = {}
+    for samples in (10, 100, 200, 300):                     # run() from the initial state to each snapshot
+        m = Fenton4vSimple(dict(cfg_s, samples=samples))
+        m.define()
+        assert np.array_equal(m.state(), np.stack([f['init_' + k] for k in 'UVWS']))
+        m.run(None)
+        got[samples] = m.state()
+        for k, n in enumerate('UVWS'):
+            assert_close(got[samples][k], f['%s_t%d' % (n, samples)], 2e-5 if samples <= 100 else 1e-4,
+                         'fenton_simple %s t%d' % (n, samples), scale=1.0)
+    assert 'elapsed' in capsys.readouterr().out and (tmp_path / 'timeline_simple.json').exists()
+    # fused (10 steps per launch when S2 and the end fall on multiples of 10) and one step per launch: bit-identical
+    res = []
+    for force1 in (False, True):
+        m = Fenton4vSimple(dict(cfg_s, samples=300, s2_time=14.9))
+        m.define()
+        assert m._s2_step == 149 and m._spt == 10
+        if force1:
+            m._chunk = lambda with_frames: 1
+        m.run(None)
+        assert m._stepper.launch_plan() == ((1, 1) if force1 else (10, 1))
+        res.append(m.state())
+    assert np.array_equal(res[0], res[1])
+
+
+def test_fenton_jit_with_screen(gpu_lib, tmp_path):
+    """run(im): a frame of the RAW potential after every dt_per_plot-th step (fenton_simple.py:195-197); the class
+    of fenton_jit.py is the same model"""
+    from fib_tf_amd.fenton_jit import Fenton4vJIT
+    from fib_tf_amd.screen import Screen
+    m = Fenton4vJIT({'width': 64, 'height': 48, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.5, 'samples': 100,
+                     's2_time': 5.0, 'timeline_name': str(tmp_path / 't.json')})
+    m.define()
+    im = Screen(48, 64, 'jit', keep=100)
+    m.run(im)
+    assert im.count == 10 and m._spt == 1                  # frames after steps 0, 10, ..., 90: no fusion possible
+    assert np.array_equal(im.frames[-1].shape, (48, 64))
+    ref = Fenton4vJIT({'width': 64, 'height': 48, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.5, 'samples': 100,
+                       's2_time': 5.0, 'timeline_name': str(tmp_path / 't2.json')})
+    ref.define()
+    ref.run(None)
+    assert np.array_equal(ref.state(), m.state())

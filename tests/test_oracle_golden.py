@@ -216,3 +216,23 @@ def test_court_ultra_us_trajectory(orc, golden):
     # 1 - tanh(x) cancels for V >> -83 mV: one ulp of tanh is an absolute 6e-8 in alpha_us/3e-5
     assert np.allclose(a, f['us_sweep_us_infinity'], rtol=3e-6, atol=3e-7)
     assert np.allclose(b, f['us_sweep_tau_us'], rtol=3e-6, atol=0)
+
+
+def test_fenton_simple_trajectory(orc, golden):
+    """fenton_simple.py: zero-padded convolution Laplacian, its own S2 op on [:H//2, :W//2]"""
+    f = golden('fenton_simple_traj')
+    s = np.stack([f['init_' + k] for k in 'UVWS']).copy()
+    H, W = s[0].shape
+    t0 = 0
+    for t in [int(x) for x in f['snap_steps']]:
+        for i in range(t0, t):
+            orc.fenton_simple_run(s, 0.1, float(f['diff']), 1)
+            if i == int(f['s2_step']):
+                s2 = np.zeros_like(s[0])
+                s2[:H // 2, :W // 2] = 1.0
+                s[0] = np.maximum(s[0], s2)
+        t0 = t
+        for k, n in enumerate('UVWS'):
+            close(s[k], f['%s_t%d' % (n, t)], 1e-6, 1.0, 'fenton_simple %s t%d' % (n, t))
+    # the outermost ring is where the variant differs from fenton.py: check that the fixture really exercises it
+    assert abs(float(f['U_t10'][0, 2]) - float(f['U_t10'][1, 2])) > 0.05
