@@ -115,6 +115,8 @@ static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
     return hipGetLastError();
 }
 
+constexpr int VM_FENTON_ZP = 100;   // variant-table id of FentonZP (not a fibhip_model: selected by FIBHIP_ZEROPAD)
+
 struct Variant {
     int model, mode, fast, phase;
     int K, TX, TY, NT;
@@ -173,6 +175,11 @@ static const Variant g_variants[] = {
     V4(Fenton, FIBHIP_FENTON4V, 0, 2, 32, 32, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 4, 256),
     V4(Fenton, FIBHIP_FENTON4V, 0, 1, 64, 16, 256),
+    // ---- Fenton 4v with the zero-padded convolution Laplacian (FIBHIP_ZEROPAD), flat kernels only ----
+    V4(FentonZP, VM_FENTON_ZP, 0, 10, 32, 32, 1024),
+    V4(FentonZP, VM_FENTON_ZP, 0, 5, 32, 32, 512),
+    V4(FentonZP, VM_FENTON_ZP, 0, 2, 64, 16, 256),
+    V4(FentonZP, VM_FENTON_ZP, 0, 1, 64, 4, 256),
 #endif
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
@@ -308,10 +315,11 @@ static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /
 {
     const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
     if (mode < 0) mode = h->mode;
+    // fenton_simple.py's Laplacian is a property of the kernel's model type (FentonZP): its own rows of the table
+    const int vmodel = (h->d.model == FIBHIP_FENTON4V && (h->d.flags & FIBHIP_ZEROPAD)) ? VM_FENTON_ZP : h->d.model;
     for (int i = 0; i < g_nvariants; ++i) {
         const Variant &v = g_variants[i];
-        if (v.model != h->d.model || v.mode != mode || v.fast != fast || v.phase != phase || v.K != K) continue;
-        if ((h->d.flags & FIBHIP_ZEROPAD) && v.NT < 0) continue;   // the zero-padded Laplacian lives in tick_kernel only
+        if (v.model != vmodel || v.mode != mode || v.fast != fast || v.phase != phase || v.K != K) continue;
         if (want && (v.TX != want[0] || v.TY != want[1] || v.NT != want[2])) continue;
         return &v;
     }
@@ -493,6 +501,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     const int ming = (desc->ghost_top && desc->ghost_bottom)
                          ? (desc->ghost_top < desc->ghost_bottom ? desc->ghost_top : desc->ghost_bottom)
                          : (desc->ghost_top ? desc->ghost_top : desc->ghost_bottom);
+    if ((desc->flags & FIBHIP_ZEROPAD) && desc->model != FIBHIP_FENTON4V)
+        return fail(FIBHIP_EINVAL, "FIBHIP_ZEROPAD exists for the Fenton 4v model only (fenton_simple.py)");
     if ((desc->flags & FIBHIP_ZEROPAD) && (desc->ghost_top || desc->ghost_bottom))
         return fail(FIBHIP_EINVAL, "FIBHIP_ZEROPAD is a single-device option (no row blocks)");
     if ((desc->ghost_top || desc->ghost_bottom) && ming < h->spt)
@@ -604,7 +614,6 @@ static Geo base_geo(const fibhip_ctx *h)
     g.rb0 = g.rb1 = 0;
     g.ty_a = 0;
     g.tiles_x = g.ntiles = 0;
-    g.zeropad = (h->d.flags & FIBHIP_ZEROPAD) ? 1 : 0;
     return g;
 }
 
@@ -1082,7 +1091,7 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
         if (phi) {
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
-            g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0; g.zeropad = 0;
+            g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
             hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
         }
         const float mdt = (float)(-dt);

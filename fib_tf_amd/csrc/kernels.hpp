@@ -37,8 +37,6 @@ struct Geo {
     int rb0, rb1;    // ... and, when ty_a < tile rows, a second band [rb0, rb1) served by the same launch
     int ty_a;        //     (the two edge strips of a row block); tile rows >= ty_a belong to the second band
     int tiles_x, ntiles;
-    int zeropad;     // FIBHIP_ZEROPAD: the Laplacian of fenton_simple.py — taps outside the grid read 0 and the nine
-                     // products are accumulated in the kernel's row-major order (tick_kernel only)
 };
 
 // tile row `by` -> first local row of the tile and the end of the band it belongs to
@@ -115,6 +113,18 @@ static FIB_DEV int xcd_tile(int b, int ntiles)
     return (b & 7) * per + (b >> 3);
 }
 
+// FIBHIP_ZEROPAD — the Laplacian of fenton_simple.py: taps outside the grid read 0 and the nine products are
+// accumulated in the kernel's row-major order.  A compile-time property of the model type (FentonZP), so that the
+// other models' kernels carry none of it; tick_kernel only.
+template <class M, class = void>
+struct ZeroPadOf {
+    static constexpr bool value = false;
+};
+template <class M>
+struct ZeroPadOf<M, std::void_t<decltype(M::ZEROPAD)>> {
+    static constexpr bool value = M::ZEROPAD;
+};
+
 // does MODE ask for two evaluations in one launch (Courtemanche::MODE_FASTSLOW)?
 template <class M, class = void>
 struct TwoPass {
@@ -139,6 +149,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
     constexpr int NC = CX * CY, CPT = (NC + NT - 1) / NT, NL = LP * LQ;
     constexpr unsigned WMASK = M::mask(MODE);
     constexpr bool PHI_TILE = PHASE && K == 1;
+    constexpr bool ZP = ZeroPadOf<M>::value;
     __shared__ float lds[(K > 1) ? 2 : 1][NL];
     __shared__ float lphi[PHI_TILE ? NL : 1];
 
@@ -160,7 +171,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         yy = clampi(yy, 0, g.H - 1);                               // stay inside this slab
         const int xx = clampi(cx0 - 1 + lx, 1, g.W - 2);
         float v = vin[(size_t)yy * g.pitch + xx];
-        if (g.zeropad) {                                           // outside the grid: 0 (conv2d padding='SAME')
+        if (ZP) {                                                  // outside the grid: 0 (conv2d padding='SAME')
             const int gyy = cy0 - 1 + ly + g.row_off, gxx = cx0 - 1 + lx;
             if (gyy < 0 || gyy > g.Hg - 1 || gxx < 0 || gxx > g.W - 1) v = 0.0f;
         }
@@ -207,7 +218,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
             f |= F_ACTIVE;
             if (!border) {
                 f |= F_WLDS;
-                const bool ghost = !g.zeropad;                     // the cells beyond the border stay 0 there
+                constexpr bool ghost = !ZP;                        // the cells beyond the border stay 0 there
                 if (gyg == 1) f |= F_TOP | (cyy >= 1 && ghost ? F_TOP2 : 0u);
                 if (gyg == g.Hg - 2) f |= F_BOT | (cyy <= CY - 2 && ghost ? F_BOT2 : 0u);
                 if (gx == 1) f |= F_LEFT | (cxx >= 1 && ghost ? F_LEFT2 : 0u);
@@ -231,8 +242,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float N = A[i - LP], S = A[i + LP], Wv = A[i - 1], E = A[i + 1];
                 const float NW = A[i - LP - 1], SW = A[i + LP - 1], NE = A[i - LP + 1], SE = A[i + LP + 1];
                 const float C = A[i];
-                float l = g.zeropad ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C)
-                                    : stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
+                float l = ZP ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C) : stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
                 if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + phase_term, IEEE division
                     const float dy = lphi[i + LP] - lphi[i - LP], dx = lphi[i + 1] - lphi[i - 1];
                     l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);

@@ -291,6 +291,11 @@ struct Fenton {
     }
 };
 
+// the same kinetics behind fenton_simple.py's zero-padded convolution Laplacian (kernels.hpp ZeroPadOf)
+struct FentonZP : Fenton {
+    static constexpr bool ZEROPAD = true;
+};
+
 // =====================================================================================
 // Beeler-Reuter  (br.py:125-332)
 // =====================================================================================
