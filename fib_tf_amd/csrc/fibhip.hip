@@ -474,6 +474,11 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     if ((desc->ghost_top > 0) != (desc->row_offset > 0) ||
         (desc->ghost_bottom > 0) != (desc->row_offset + desc->height < Hg))
         return fail(FIBHIP_EINVAL, "ghost rows must exist exactly on the sides that have a neighbour");
+    {   // the kernels index with 32-bit ints: rows * (floats between rows) of one array view must stay below 2^31
+        const long long pitch = (desc->flags & FIBHIP_ROW_INTERLEAVED) ? (long long)nv * desc->width : desc->width;
+        if ((long long)desc->height * pitch >= (1LL << 31))
+            return fail(FIBHIP_EINVAL, "grid too large for 32-bit indexing: %d rows x %lld floats per row", desc->height, pitch);
+    }
     if (!(desc->dt > 0.0)) return fail(FIBHIP_EINVAL, "dt must be positive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

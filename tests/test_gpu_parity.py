@@ -778,3 +778,19 @@ def test_fenton_jit_with_screen(gpu_lib, tmp_path):
     ref.define()
     ref.run(None)
     assert np.array_equal(ref.state(), m.state())
+
+
+def test_create_rejects_what_the_kernels_cannot_index(gpu_lib):
+    """32-bit index arithmetic inside the kernels: a grid whose array view reaches 2^31 floats is refused at create
+    time (before any allocation), as are the other malformed descriptions"""
+    from fib_tf_amd import _lib
+    with pytest.raises(_lib.FibhipError, match='32-bit'):
+        _lib.Stepper(_lib.FENTON4V, 65536, 32768, 0.1, 1.0)
+    with pytest.raises(_lib.FibhipError, match='at least 3x3'):
+        _lib.Stepper(_lib.FENTON4V, 2, 100, 0.1, 1.0)
+    with pytest.raises(_lib.FibhipError, match='dt must be positive'):
+        _lib.Stepper(_lib.FENTON4V, 32, 32, 0.0, 1.0)
+    with pytest.raises(_lib.FibhipError, match='Fenton 4v model only'):
+        _lib.Stepper(_lib.BR, 32, 32, 0.1, 1.0, flags=_lib.ZEROPAD)
+    with pytest.raises(_lib.FibhipError, match='unknown model'):
+        _lib.Stepper(17, 32, 32, 0.1, 1.0)
