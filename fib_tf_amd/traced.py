@@ -629,6 +629,7 @@ def generate(programs, nslots, remap, spt):
            '#define FIB_CUSTOM_TX %d' % (TX if fuse else 64),
            '#define FIB_CUSTOM_TY %d' % (TY if fuse else 4),
            '#define FIB_CUSTOM_R %d' % R,
+           '#define FIB_CUSTOM_TYB %d' % ((15 * R - 2 * K) if fuse and 15 * R - 2 * K >= 6 else 0),   # one wave fewer per tile
            '#define FIB_CUSTOM_K2 %d' % K2,
            '#define FIB_CUSTOM_TX2 %d' % TX2,
            '#define FIB_CUSTOM_TY2 %d' % TY2,
