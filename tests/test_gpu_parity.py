@@ -794,3 +794,36 @@ def test_create_rejects_what_the_kernels_cannot_index(gpu_lib):
         _lib.Stepper(_lib.BR, 32, 32, 0.1, 1.0, flags=_lib.ZEROPAD)
     with pytest.raises(_lib.FibhipError, match='unknown model'):
         _lib.Stepper(17, 32, 32, 0.1, 1.0)
+
+
+def test_court_fused_slow_tick_small_shapes(gpu_lib, monkeypatch):
+    """the one-launch tick + slow on awkward grids (3 rows, 3 columns, sizes around the 64x4 tile edges): same bits as
+    the two-launch path; raw C ABI so that many shapes stay cheap"""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.court import INITIAL
+    rng = np.random.default_rng(7)
+    shapes = [(3, 3), (3, 70), (70, 3), (4, 64), (5, 65), (6, 7), (8, 128), (9, 129), (13, 66), (66, 130), (7, 191)]
+    for H, W in shapes:
+        init = np.empty((21, H, W), np.float32)
+        for i, (_, v) in enumerate(INITIAL):
+            init[i] = v
+        init[0] += rng.uniform(-5, 30, (H, W)).astype(np.float32)
+        phi = rng.uniform(0.3, 1.0, (H, W)).astype(np.float32)
+        out = []
+        for lazy in (True, False):
+            if lazy:
+                monkeypatch.delenv('FIBHIP_NO_LAZY', raising=False)
+            else:
+                monkeypatch.setenv('FIBHIP_NO_LAZY', '1')
+            st = _lib.Stepper(_lib.COURT, H, W, 0.1, 0.809, flags=_lib.FAST | _lib.CHRONIC)
+            st.set_phase(phi)
+            st.set_state(-1, init)
+            for i in range(23):
+                st.step(1)
+                if i % 10 == 0:
+                    st.step_slow()
+                if i == 12:
+                    st.pace(0, max(1, H // 2), 0, max(1, W // 2), 10.0, -100.0)
+            out.append(st.get_state(-1))
+            st.close()
+        assert np.array_equal(out[0], out[1]), (H, W)
