@@ -97,6 +97,11 @@ CASES = [
          'halo_ticks': 3}),
     (3, {'model': 'court', 'H': 45, 'W': 56, 'diff': 0.809, 'hole': (28, 20, 5), 'ticks': 23, 's2': 11, 'amp': 10.0,
          'halo_ticks': 1}),
+    # more ranks: interior ranks with two neighbours on both sides, uneven blocks
+    (4, {'model': 'fenton', 'H': 103, 'W': 33, 'diff': 1.5, 'hole': (16, 50, 6), 'ticks': 7, 's2': 3, 'amp': 1.0,
+         'halo_ticks': 2}),
+    (5, {'model': 'br', 'H': 73, 'W': 21, 'diff': 0.809, 'hole': (10, 36, 4), 'ticks': 6, 's2': 2, 'amp': 10.0,
+         'cheby': True, 'skip': False, 'halo_ticks': 2}),
 ]
 
 
