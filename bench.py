@@ -196,6 +196,12 @@ def bench_single(args):
                      'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
                              'one-step-per-pass implementation must move, K fused sub-steps move them once'},
     }
+    try:                                              # achievable-bandwidth yardstick, measured in this very run
+        from fib_tf_amd import _lib
+        out['roofline']['copy_bandwidth_measured'] = round(_lib.copy_bandwidth(1 << 30, 5, m.device), 1)
+    except Exception as e:                            # never lose the result line over the yardstick
+        out['roofline']['copy_bandwidth_measured'] = None
+        print('copy bandwidth not measured: %s' % e, file=sys.stderr)
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args)
     return out

@@ -69,6 +69,7 @@ SYMBOLS = {
     'fibhip_unit_op': ([C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_double, C.c_int, _fp],
                        C.c_int),
     'fibhip_court_inter': ([C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
+    'fibhip_copy_bandwidth': ([C.c_int, C.c_size_t, C.c_int, _fp], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -175,6 +176,13 @@ COURT_INTER_KEYS = ('d_infinity', 'tau_d', 'f_infinity', 'tau_f', 'tau_w', 'w_in
                     'tau_h', 'j_inf', 'tau_j', 'tau_oa', 'oa_infinity', 'tau_oi', 'oi_infinity', 'tau_ua',
                     'ua_infinity', 'tau_ui', 'ui_infinity', 'tau_xr', 'xr_infinity', 'tau_xs', 'xs_infinity', 'g_Kur',
                     'f_NaK', 'i_NaCaa', 'i_NaCab', 'i_K1a', 'i_Kra', 'us_infinity', 'tau_us')
+
+
+def copy_bandwidth(nbytes=1 << 30, reps=5, device=0):
+    """GB/s (read + written) of a plain streaming copy on the device: the achievable-HBM yardstick"""
+    out = C.c_float()
+    check(lib().fibhip_copy_bandwidth(device, nbytes, reps, C.byref(out)))
+    return out.value
 
 
 def court_inter(V, fast=False, device=0):

@@ -1152,6 +1152,45 @@ extern "C" int fibhip_court_inter(int device, int n, const float *V, int fast, f
     return rc;
 }
 
+extern "C" int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gbs)
+{
+    if (!gbs || nbytes < (1u << 20) || reps < 1) return fail(FIBHIP_EINVAL, "copy_bandwidth: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    const size_t n = nbytes / sizeof(fib_v4f);
+    fib_v4f *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        if (hipMalloc((void **)&a, n * sizeof(fib_v4f)) != hipSuccess || hipMalloc((void **)&b, n * sizeof(fib_v4f)) != hipSuccess ||
+            hipMemset(a, 0, n * sizeof(fib_v4f)) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+            hipEventCreate(&e1) != hipSuccess) {
+            rc = fail(FIBHIP_EHIP, "copy_bandwidth: allocation failed");
+            break;
+        }
+        const int grid = 256 * 16;                         // 16 workgroups per CU
+        hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n);   // warm-up
+        float best = 1e30f;
+        for (int r = 0; r < reps; ++r) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n);
+            hipEventRecord(e1, 0);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(FIBHIP_EHIP, "copy_bandwidth: kernel failed"); break; }
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        if (!rc) *gbs = (float)(2.0 * (double)(n * sizeof(fib_v4f)) / (best * 1e-3) / 1e9);   // bytes read + written
+    } while (0);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    return rc;
+}
+
 extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");

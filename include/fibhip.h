@@ -171,6 +171,10 @@ int fibhip_unit_op(int device, int op, int height, int width, const float *a, co
  * d_infinity tau_d f_infinity tau_f tau_w w_infinity m_inf tau_m h_inf tau_h j_inf tau_j tau_oa oa_infinity
  * tau_oi oi_infinity tau_ua ua_infinity tau_ui ui_infinity tau_xr xr_infinity tau_xs xs_infinity g_Kur f_NaK
  * i_NaCaa i_NaCab i_K1a i_Kra us_infinity tau_us   (FIBHIP_COURT_NINTER = 32 rows)                        */
+/* measurement aid: best-of-`reps` rate of a plain device-to-device streaming copy of nbytes (read + written bytes
+ * per second, GB/s) — the achievable-bandwidth yardstick printed next to the roofline peak                  */
+int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gb_per_s);
+
 #define FIBHIP_COURT_NINTER 32
 int fibhip_court_inter(int device, int n, const float *V, int fast, float *out);
 
