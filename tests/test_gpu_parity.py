@@ -827,3 +827,12 @@ def test_court_fused_slow_tick_small_shapes(gpu_lib, monkeypatch):
             out.append(st.get_state(-1))
             st.close()
         assert np.array_equal(out[0], out[1]), (H, W)
+
+
+def test_copy_bandwidth_yardstick(gpu_lib):
+    """fibhip_copy_bandwidth: the plain streaming copy bench.py reports next to the roofline peak"""
+    from fib_tf_amd import _lib
+    gbs = _lib.copy_bandwidth(1 << 28, 3)
+    assert 500.0 < gbs < 8000.0, gbs                       # an MI355X does several TB/s; 8 TB/s is the HBM3E peak
+    with pytest.raises(_lib.FibhipError):
+        _lib.copy_bandwidth(1024, 1)
