@@ -117,3 +117,28 @@ def test_fenton_reentry_fast_vs_exact(gpu_lib):
     assert np.abs(fast - exact).max() <= 1, (fast, exact)
     cl_f, cl_e = np.diff(fast)[1:], np.diff(exact)[1:]
     assert abs(cl_f.mean() - cl_e.mean()) <= 1.0 and 60 < cl_f.mean() < 400, (cl_f, cl_e)
+
+
+def test_fenton_config1_full_run_gpu_vs_oracle(gpu_lib, orc):
+    """BASELINE configs[0] vs configs[1]: the reference's whole fenton.py job (512x512, 1000 ms = 10 000 sub-steps,
+    obstacle, S1, S2 at 210 ms) on the CPU oracle and on the GPU (default policy): the same wave passages at the
+    watched pixel, millisecond for millisecond"""
+    from fib_tf_amd.fenton import Fenton4v
+    gpu = _reentry_cycle_lengths('fast')
+    m = Fenton4v({'height': 512, 'width': 512, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.5, 'duration': 1000})
+    m.add_hole_to_phase_field(256, 256, 30)
+    rect = m.pace_rect('luq')
+    s = np.zeros((4, 512, 512), np.float32)
+    s[1:3] = 1.0
+    s[0][:, 1] = 1.0
+    ups, prev = [], 0.0
+    for i in range(1000):
+        orc.fenton_run(s, 0.1, 1.5, m.phase, 10)
+        if i == 210:
+            s[0] = orc.pace(s[0], *rect, 1.0, 0.0)
+        v = float(s[0][20, 256])
+        if v >= 0.5 > prev:
+            ups.append(i)
+        prev = v
+    ups = np.array(ups)
+    assert len(ups) == len(gpu) >= 4 and np.abs(ups - gpu).max() <= 1, (ups, gpu)
