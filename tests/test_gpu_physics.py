@@ -142,3 +142,43 @@ def test_fenton_config1_full_run_gpu_vs_oracle(gpu_lib, orc):
         prev = v
     ups = np.array(ups)
     assert len(ups) == len(gpu) >= 4 and np.abs(ups - gpu).max() <= 1, (ups, gpu)
+
+
+def test_br_config3_full_run_gpu_vs_oracle(gpu_lib, orc):
+    """BASELINE configs[2]: the reference's whole br.py job (br.py:348-382: 512x512, cheby=True, diff 0.809, obstacle
+    (150,200,40), S2 'luq' 10 mV at tick 600, 1000 ms = 2000 ticks of 5 sub-steps) on the CPU oracle and on the GPU
+    (default policy, table-specialised build, 5 sub-steps per launch): upstrokes through -30 mV (image() = 0.5) at
+    the watched pixel within 1 ms of each other"""
+    from fib_tf_amd.br import BeelerReuter
+    cfg = {'height': 512, 'width': 512, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 0.809, 'duration': 1000, 'skip': False,
+           'cheby': True}
+    m = BeelerReuter(cfg)
+    m.add_hole_to_phase_field(150, 200, 40)
+    m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
+    st = m._stepper
+    gpu, prev = [], -90.0
+    for i in m.run():
+        if i == 600:
+            m.fire_op('s2')
+        v = float(st.probe(0, 20, 256))
+        if v >= -30.0 > prev:
+            gpu.append(i)
+        prev = v
+    tbl = m.chebyshev_table().astype(np.float32)
+    rect = m.pace_rect('luq')
+    s = np.empty((8, 512, 512), np.float32)
+    for k, v in enumerate((-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)):
+        s[k] = v
+    s[0][:, 1] = 10.0
+    cpu, prev = [], -90.0
+    for i in range(2000):
+        orc.br_run(s, 0.1, 0.809, m.phase, tbl, False, 1)
+        if i == 600:
+            s[0] = orc.pace(s[0], *rect, 10.0, -90.0)
+        v = float(s[0][20, 256])
+        if v >= -30.0 > prev:
+            cpu.append(i)
+        prev = v
+    gpu, cpu = np.array(gpu), np.array(cpu)
+    assert len(gpu) == len(cpu) >= 2 and np.abs(gpu - cpu).max() <= 2, (gpu, cpu)       # ticks of 0.5 ms
