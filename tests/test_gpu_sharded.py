@@ -83,3 +83,17 @@ def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split,
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
     if case['model'] in ('court', 'gated'):
         assert np.array_equal(out['trend'], trend)
+
+
+def test_rccl_self_exchange_on_slab_views(gpu_lib, tmp_path):
+    """the RCCL leg itself, as far as one GPU can run it: backend nccl, one rank, the production P2POp pattern on the
+    engine's slab views and stream, sent to itself (tests/rccl_self_worker.py)"""
+    import subprocess
+    from test_sharded_cpu import free_port
+    out = str(tmp_path / 'ok.npy')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_self_worker.py'),
+                        str(free_port()), out], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok = np.load(out)
+    assert ok.all(), ok
