@@ -343,7 +343,9 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                 m.fire_op('s2')
             tick += 1
 
-    advance(st.halo_ticks)                              # setup, not warm-up: one full exchange cycle creates
+    # (a one-rank group — only ever used to rehearse this path on one GPU — has a plain Stepper: no ghost zone)
+    halo_ticks, ghost, halo_n = getattr(st, 'halo_ticks', 1), getattr(st, 'g', 0), getattr(st, 'halo_n', 0)
+    advance(halo_ticks)                                 # setup, not warm-up: one full exchange cycle creates
     st.sync()                                           # the RCCL channels and loads the code objects
     advance(args.warmup)
     st.sync()
@@ -357,7 +359,7 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall = float(wall.item())
-    comm = torch.tensor([st.comm_s], dtype=torch.float64, device='cuda')
+    comm = torch.tensor([getattr(st, 'comm_s', 0.0)], dtype=torch.float64, device='cuda')
     dist.all_reduce(comm, op=dist.ReduceOp.MAX)
     fused, per_tick = st.launch_plan()
     out = None
@@ -379,8 +381,7 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one RCCL send/recv pair per '
                                       'neighbour every %d ticks, %d arrays in one contiguous message, interior '
-                                      'overlapped on a second stream' % (world, st.g, st.halo_ticks, st.halo_ticks,
-                                                                         st.halo_n),
+                                      'overlapped on a second stream' % (world, ghost, halo_ticks, halo_ticks, halo_n),
                        'halo_wait_s_max_rank': round(float(comm.item()), 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': round(achieved / hbm_peak, 4), 'traffic': None,

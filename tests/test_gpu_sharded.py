@@ -97,3 +97,21 @@ def test_rccl_self_exchange_on_slab_views(gpu_lib, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     ok = np.load(out)
     assert ok.all(), ok
+
+
+def test_bench_sharded_on_rccl_backend_single_rank(gpu_lib):
+    """bench.py's multi-rank branch on the real backend with a one-rank group: process-group init with device_id,
+    barriers, the MAX all-reduce of the timing, the result line (what two RCCL ranks would add is only the halo
+    messages themselves, covered by the self-exchange test above)"""
+    import json
+    import subprocess
+    from test_sharded_cpu import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('FIBTF_DIST_BACKEND', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '200', '--warmup', '20'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['value'] > 1000 and line['scaling'] == 'weak'
