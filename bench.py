@@ -43,7 +43,8 @@ def make_model(args, height=None, device=0):
     H = height or S
     sc = S / 512.0
     base = {'width': S, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'timeline': False,
-            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not args.exact}
+            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not args.exact,
+            'halo_ticks': getattr(args, 'halo_ticks', 4)}
     if args.model == 'fenton':                        # fenton.py:156-171
         m = Fenton4v(dict(base, diff=1.5))
         m.add_hole_to_phase_field(256 * sc, H / 2.0, 30 * sc)
@@ -222,6 +223,7 @@ def main():
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--halo-ticks', type=int, default=4, help='N > 1: ticks between two halo exchanges (ghost zone depth)')
     args = ap.parse_args()
     if not args.size:
         args.size = 1024 if args.model == 'court' else 512
