@@ -36,6 +36,10 @@ class Desc(C.Structure):
                 ('ext_slab', C.c_void_p * 2)]
 
 
+class HaloMsg(C.Structure):
+    _fields_ = [('offset', C.c_longlong), ('count', C.c_longlong), ('peer', C.c_int), ('send', C.c_int)]
+
+
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 _h = C.c_void_p
@@ -69,6 +73,12 @@ SYMBOLS = {
     'fibhip_unit_op': ([C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_double, C.c_int, _fp],
                        C.c_int),
     'fibhip_court_inter': ([C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
+    'fibhip_halo_plan': ([_h, C.c_int, C.c_int, C.POINTER(HaloMsg), _ip], C.c_int),
+    'fibhip_comm_open': ([C.c_char_p], C.c_int),
+    'fibhip_comm_unique_id': ([C.c_char_p], C.c_int),
+    'fibhip_comm_init': ([_h, C.c_char_p, C.c_int, C.c_int], C.c_int),
+    'fibhip_comm_exchange': ([_h, C.c_int, C.c_int], C.c_int),
+    'fibhip_comm_free': ([_h], C.c_int),
     'fibhip_copy_bandwidth': ([C.c_int, C.c_size_t, C.c_int, _fp], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
@@ -299,6 +309,35 @@ class Stepper:
 
     def halo_due(self):
         return bool(self._ck(self._L.fibhip_halo_due(self._h)))
+
+    # ---- direct halo exchange (RCCL issued by the library on this handle's stream) ------------------------
+    def comm_open(self, librccl_path=None):
+        self._ck(self._L.fibhip_comm_open(librccl_path.encode() if librccl_path else None))
+
+    def comm_unique_id(self, librccl_path=None):
+        self.comm_open(librccl_path)
+        buf = C.create_string_buffer(128)
+        self._ck(self._L.fibhip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks, librccl_path=None):
+        self._ck(self._L.fibhip_comm_open(librccl_path.encode() if librccl_path else None))
+        assert len(unique_id) == 128
+        self._ck(self._L.fibhip_comm_init(self._h, unique_id, rank, nranks))
+
+    def halo_plan(self, up, down):
+        """[(offset, count, peer, send)], slab index: the messages of this exchange tick (include/fibhip.h)"""
+        msg = (HaloMsg * 4)()
+        idx = C.c_int()
+        n = self._ck(self._L.fibhip_halo_plan(self._h, -1 if up is None else up, -1 if down is None else down, msg,
+                                              C.byref(idx)))
+        return [(m.offset, m.count, m.peer, bool(m.send)) for m in msg[:n]], idx.value
+
+    def comm_free(self):
+        self._L.fibhip_comm_free(self._h)
+
+    def comm_exchange(self, up, down):
+        self._ck(self._L.fibhip_comm_exchange(self._h, -1 if up is None else up, -1 if down is None else down))
 
     def launch_plan(self):
         k, n = C.c_int(), C.c_int()

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -261,6 +262,7 @@ struct fibhip_ctx {
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
                             // cpos = ticks done since the last exchange
+    void *comm;             // ncclComm_t of the direct halo path (fibhip_comm_*), or null
     float *probe_host;      // pinned
     float *stage;           // pinned staging buffer for get_state/set_state (one array), allocated on first use
 };
@@ -591,12 +593,16 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->launches = 0;
     h->pending = false;
     h->fused_fn = nullptr;
+    h->comm = nullptr;
     return build_plan(h);
 }
+
+extern "C" int fibhip_comm_free(fibhip_t h);
 
 extern "C" int fibhip_destroy(fibhip_t h)
 {
     if (!h) return 0;
+    fibhip_comm_free(h);
     hipSetDevice(h->d.device);
     if (h->s0) hipStreamSynchronize(h->s0);
     if (h->s1) hipStreamSynchronize(h->s1);
@@ -1150,6 +1156,154 @@ extern "C" int fibhip_court_inter(int device, int n, const float *V, int fast, f
     } while (0);
     hipFree(d);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Direct halo exchange: ncclSend / ncclRecv issued from here, on the handle's own stream, grouped into one RCCL
+// kernel per exchange — no torch enqueue path (55-70 us of host time per exchange, tools/p2p_overhead.py) and no
+// hop to a communication stream and back.  RCCL is bound at run time (dlopen) so that the library has no link-time
+// dependency on it; the caller passes the path of the librccl its process already uses (torch's).  Opt-in:
+// fib_tf_amd/sharded.py uses this path when FIBTF_HALO=direct.
+// ------------------------------------------------------------------------------------------
+struct FibNcclId {
+    char internal[128];                                     // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+};
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, FibNcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static RcclApi g_rccl;
+constexpr int FIB_NCCL_FLOAT = 7;                           // ncclFloat32 (rccl.h)
+
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        const int rc_ = (expr);                                                                    \
+        if (rc_ != 0)                                                                              \
+            return fail(FIBHIP_EHIP, "RCCL: %s failed: %s", #expr,                                 \
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(rc_) : "?");                 \
+    } while (0)
+
+extern "C" int fibhip_comm_open(const char *librccl_path)
+{
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);         // the copy this process already runs
+    if (!lib && librccl_path) lib = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(FIBHIP_EINVAL, "comm_open: librccl not loaded and not found at %s", librccl_path ? librccl_path : "(null)");
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, FibNcclId, int))dlsym(lib, "ncclCommInitRank");
+    a.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    a.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+    a.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+    a.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclSend");
+    a.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclRecv");
+    a.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv)
+        return fail(FIBHIP_EINVAL, "comm_open: librccl lacks the point-to-point API");
+    g_rccl = a;
+    return 0;
+}
+
+extern "C" int fibhip_comm_unique_id(char *out128)
+{
+    if (!out128) return fail(FIBHIP_EINVAL, "comm_unique_id: null argument");
+    if (!g_rccl.lib) return fail(FIBHIP_EINVAL, "comm_unique_id: call fibhip_comm_open first");
+    FibNcclId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out128, id.internal, sizeof id.internal);
+    return 0;
+}
+
+extern "C" int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks)
+{
+    NEED(h);
+    if (!id128 || rank < 0 || rank >= nranks) return fail(FIBHIP_EINVAL, "comm_init: bad argument");
+    if (!g_rccl.lib) return fail(FIBHIP_EINVAL, "comm_init: call fibhip_comm_open first");
+    if (h->comm) return fail(FIBHIP_EINVAL, "comm_init: this handle already has a communicator");
+    if (!(h->d.flags & FIBHIP_ROW_INTERLEAVED))
+        return fail(FIBHIP_EINVAL, "comm_init: the direct exchange needs the row-interleaved slab (one block per message)");
+    FibNcclId id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    void *comm = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&comm, nranks, id, rank));               // collective over the `nranks` callers
+    h->comm = comm;
+    return 0;
+}
+
+// The messages of one halo exchange, as offsets into the slab the open tick writes: my outermost owned ghost-depth
+// rows of ALL arrays go to the neighbours, theirs arrive in my ghost rows, in place.  One description serves both
+// transports (fibhip_comm_exchange below; the caller's own library through fibhip_halo_plan), so that the row
+// arithmetic the multi-rank tests verify is the arithmetic RCCL executes.
+extern "C" int fibhip_halo_plan(fibhip_t h, int up_rank, int down_rank, fibhip_halo_msg *out, int *slab_index)
+{
+    NEED(h);
+    if (!out) return fail(FIBHIP_EINVAL, "halo_plan: null argument");
+    if (h->phase_of_tick != 1) return fail(FIBHIP_EINVAL, "halo_plan: call it between step_edges and step_commit");
+    if (!(h->d.flags & FIBHIP_ROW_INTERLEAVED))
+        return fail(FIBHIP_EINVAL, "halo_plan: needs the row-interleaved slab (one block per message)");
+    if ((up_rank >= 0) != (h->d.ghost_top > 0) || (down_rank >= 0) != (h->d.ghost_bottom > 0))
+        return fail(FIBHIP_EINVAL, "halo_plan: neighbours do not match the ghost rows of this block");
+    for (int v = 1; v < h->nvar; ++v)
+        if (h->nxt[v] != h->nxt[0])
+            return fail(FIBHIP_EINVAL, "halo_plan: the arrays of this tick live in different slabs (one sub-step per "
+                                       "launch without a multi-tick ghost zone): use the packed exchange");
+    const long long row = h->pitch;                                        // floats per grid row, all arrays
+    int n = 0;
+    if (up_rank >= 0) {
+        const long long cnt = (long long)h->d.ghost_top * row;
+        out[n++] = {(long long)h->own0 * row, cnt, up_rank, 1};
+        out[n++] = {0, cnt, up_rank, 0};
+    }
+    if (down_rank >= 0) {
+        const long long cnt = (long long)h->d.ghost_bottom * row;
+        out[n++] = {(long long)(h->own1 - h->d.ghost_bottom) * row, cnt, down_rank, 1};
+        out[n++] = {(long long)h->own1 * row, cnt, down_rank, 0};
+    }
+    if (slab_index) *slab_index = h->nxt[0];
+    return n;
+}
+
+// the same messages as ONE grouped RCCL kernel on the handle's stream
+extern "C" int fibhip_comm_exchange(fibhip_t h, int up_rank, int down_rank)
+{
+    NEED(h);
+    if (!h->comm) return fail(FIBHIP_EINVAL, "comm_exchange: no communicator (fibhip_comm_init)");
+    fibhip_halo_msg msg[4];
+    int idx = 0;
+    const int n = fibhip_halo_plan(h, up_rank, down_rank, msg, &idx);
+    if (n < 0) return n;
+    float *slab = h->slab[idx];
+    NCCLCHK(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        if (msg[i].send)
+            NCCLCHK(g_rccl.Send(slab + msg[i].offset, (size_t)msg[i].count, FIB_NCCL_FLOAT, msg[i].peer, h->comm, h->s0));
+        else
+            NCCLCHK(g_rccl.Recv(slab + msg[i].offset, (size_t)msg[i].count, FIB_NCCL_FLOAT, msg[i].peer, h->comm, h->s0));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return 0;
+}
+
+extern "C" int fibhip_comm_free(fibhip_t h)
+{
+    if (!h) return 0;
+    if (h->comm && g_rccl.CommDestroy) {
+        hipSetDevice(h->d.device);
+        if (h->s0) hipStreamSynchronize(h->s0);
+        g_rccl.CommDestroy(h->comm);
+    }
+    h->comm = nullptr;
+    return 0;
 }
 
 extern "C" int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gbs)

@@ -150,6 +150,47 @@ class ShardedStepper:
         self.recv_down = mk() if self.down is not None else None
         self._op_cache = {}
         self.comm_s = 0.0
+        # Halo transport on RCCL: by default the library issues ncclSend/ncclRecv itself on the compute stream
+        # (include/fibhip.h fibhip_comm_*): one C call and one RCCL kernel per exchange, 92 us per 4-tick cycle
+        # against 133 us through torch's batch_isend_irecv (tools/exchange_tick_cost.py).  FIBTF_HALO=torch forces
+        # the torch path; any rank failing to set the direct path up sends ALL ranks back to it, collectively.
+        self.rccl_direct = False
+        if (not self.staged and engine_factory is None and os.environ.get('FIBTF_HALO', 'direct') == 'direct'
+                and (self.world > 1 or os.environ.get('FIBTF_HALO_SELFTEST') == '1')):    # (self-test: one-rank group)
+            self.rccl_direct = self._setup_direct(group)
+        self.halo_path = 'library ncclSend/ncclRecv on the compute stream' if self.rccl_direct else (
+            'host-staged (no device point-to-point on this backend)' if self.staged else 'torch.distributed batch_isend_irecv')
+
+    def _agree(self, ok, group):
+        """True iff every rank says ok"""
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.eng.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    def _setup_direct(self, group):
+        torch, dist = self.torch, self.dist
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        uid, ok = None, True
+        try:                                                # bind RCCL; rank 0 draws the communicator id
+            self.eng.st.comm_open(path)
+            if self.rank == 0:
+                uid = self.eng.st.comm_unique_id(path)
+        except Exception as e:                              # noqa: BLE001  (any failure = use the other transport)
+            ok = False
+            print('fib_tf_amd.sharded: direct RCCL path unavailable on rank %d (%s)' % (self.rank, e))
+        if not self._agree(ok, group):
+            return False
+        box = [uid if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        try:
+            self.eng.st.comm_init(box[0], self.rank, self.world, path)
+        except Exception as e:                              # noqa: BLE001
+            ok = False
+            print('fib_tf_amd.sharded: communicator setup failed on rank %d (%s)' % (self.rank, e))
+        if not self._agree(ok, group):
+            self.eng.st.comm_free()
+            return False
+        return True
 
     # ---- data movement between the global arrays and this block ---------------------------------
     def _local(self, arr):
@@ -214,9 +255,34 @@ class ShardedStepper:
         t0 = time.perf_counter()
         b = self.gt + self.rows
         idxs = {e.next_buf(v)[0] for v in range(self.halo_n)}
-        direct = (not self.staged and getattr(e, 'interleaved', False) and self.halo_n == self.nvar
-                  and len(idxs) == 1)
-        if direct:
+        one_block = getattr(e, 'interleaved', False) and self.halo_n == self.nvar and len(idxs) == 1
+        direct = not self.staged and one_block
+        if self.staged and one_block and os.environ.get('FIBTF_HALO') == 'plan':
+            # test mode: the library's own message description (fibhip_halo_plan — what fibhip_comm_exchange hands
+            # to RCCL) executed through host staging, so that several ranks on ONE GPU verify its row arithmetic
+            msgs, idx = e.halo_plan(self.up, self.down)
+            self.plan_exchanges = getattr(self, 'plan_exchanges', 0) + 1
+            flat = e.slabs[idx].view(-1)
+            ops, recvs, keep = [], [], []
+            for off, cnt, peer, send in msgs:
+                if send:
+                    t = flat[off:off + cnt].cpu()
+                    keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+                else:
+                    t = torch.empty(cnt, dtype=torch.float32)
+                    recvs.append((off, cnt, t))
+                    ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            e.step_interior()
+            for r in reqs:
+                r.wait()
+            for off, cnt, t in recvs:
+                flat[off:off + cnt].copy_(t)
+        elif direct and self.rccl_direct:
+            e.comm_exchange(self.up, self.down)             # stream-ordered after the kernels of step_edges
+            e.step_interior()
+        elif direct:
             ops = self._p2p_ops(next(iter(idxs)))
             reqs = dist.batch_isend_irecv(ops) if ops else []
             e.step_interior()                               # overlaps with the messages
@@ -381,7 +447,8 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one RCCL send/recv pair per '
                                       'neighbour every %d ticks, %d arrays in one contiguous message, interior '
-                                      'overlapped on a second stream' % (world, ghost, halo_ticks, halo_ticks, halo_n),
+                                      'overlapped on a second stream; transport: %s' % (world, ghost, halo_ticks, halo_ticks, halo_n,
+                                                                                       getattr(st, 'halo_path', 'none')),
                        'halo_wait_s_max_rank': round(float(comm.item()), 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': round(achieved / hbm_peak, 4), 'traffic': None,

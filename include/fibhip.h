@@ -171,6 +171,29 @@ int fibhip_unit_op(int device, int op, int height, int width, const float *a, co
  * d_infinity tau_d f_infinity tau_f tau_w w_infinity m_inf tau_m h_inf tau_h j_inf tau_j tau_oa oa_infinity
  * tau_oi oi_infinity tau_ua ua_infinity tau_ui ui_infinity tau_xr xr_infinity tau_xs xs_infinity g_Kur f_NaK
  * i_NaCaa i_NaCab i_K1a i_Kra us_infinity tau_us   (FIBHIP_COURT_NINTER = 32 rows)                        */
+/* Direct halo exchange (opt-in, FIBTF_HALO=direct): the ghost rows move by ncclSend/ncclRecv issued by the library
+ * itself on the handle's stream, one RCCL kernel per exchange, instead of through the caller's communication
+ * library.  RCCL is bound with dlopen: pass the path of the librccl the process uses (NULL if it is already loaded).
+ *   fibhip_comm_open       once per process
+ *   fibhip_comm_unique_id  on one rank; the caller broadcasts the 128 bytes
+ *   fibhip_comm_init       collective: every rank of the group, same id
+ *   fibhip_comm_exchange   on an exchange tick (fibhip_halo_due), between step_edges and step_commit; -1 = no
+ *                          neighbour on that side.  Needs FIBHIP_ROW_INTERLEAVED (one block per message).         */
+typedef struct fibhip_halo_msg {
+    long long offset;   /* floats from the base of the slab fibhip_halo_plan names */
+    long long count;    /* floats */
+    int peer;           /* rank of the neighbour */
+    int send;           /* 1 = my rows go out, 0 = the neighbour's rows come in (my ghost rows) */
+} fibhip_halo_msg;
+/* the (at most 4) messages of one halo exchange of the open tick, in posting order; returns their number.
+ * *slab_index = which of the two slabs (ext_slab[i]) they refer to.                                              */
+int fibhip_halo_plan(fibhip_t h, int up_rank, int down_rank, fibhip_halo_msg *out4, int *slab_index);
+int fibhip_comm_open(const char *librccl_path);
+int fibhip_comm_unique_id(char *out128);
+int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks);
+int fibhip_comm_exchange(fibhip_t h, int up_rank, int down_rank);
+int fibhip_comm_free(fibhip_t h);
+
 /* measurement aid: best-of-`reps` rate of a plain device-to-device streaming copy of nbytes (read + written bytes
  * per second, GB/s) — the achievable-bandwidth yardstick printed next to the roofline peak                  */
 int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gb_per_s);

@@ -52,7 +52,8 @@ def run_case(rank, world, port, case, outdir):
         img = m.image()
         if rank == 0:
             np.savez(os.path.join(outdir, 'out.npz'), full=full, img=img, trend=np.array(trend, np.float32),
-                     blocks=np.array(m._stepper.blocks), halo_ticks=m._stepper.halo_ticks)
+                     blocks=np.array(m._stepper.blocks), halo_ticks=m._stepper.halo_ticks,
+                     plan_exchanges=getattr(m._stepper, 'plan_exchanges', 0))
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -115,3 +115,29 @@ def test_bench_sharded_on_rccl_backend_single_rank(gpu_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 1000 and line['scaling'] == 'weak'
+
+
+def test_direct_rccl_exchange_self(gpu_lib, tmp_path):
+    """the opt-in direct halo path (FIBTF_HALO=direct): RCCL bound with dlopen, communicator created by the library,
+    one grouped ncclSend/ncclRecv exchange on the handle's stream — with a one-rank communicator (tests/rccl_direct_worker.py)"""
+    import subprocess
+    out = str(tmp_path / 'ok.npy')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_direct_worker.py'), out],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.load(out).all()
+
+
+@pytest.mark.parametrize('world,case', [c for c in CASES if c[1]['model'] in ('fenton', 'br', 'ap')][:6],
+                         ids=lambda v: str(v) if isinstance(v, int) else v['model'] + str(v['H']))
+def test_library_halo_messages_equal_single_handle(gpu_lib, world, case, tmp_path, monkeypatch):
+    """FIBTF_HALO=plan: the exchange executes the message list the C library builds for its own RCCL transport
+    (fibhip_halo_plan: which rows of the interleaved slab go to / come from which rank) through host staging —
+    with 2-4 ranks on the one GPU the result must equal the single-handle run bit for bit"""
+    monkeypatch.setenv('FIBTF_HALO', 'plan')
+    monkeypatch.delenv('FIBHIP_SPLIT', raising=False)
+    want, _ = single(case)
+    out = launch(world, dict(case, engine='hip'), tmp_path)
+    assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
+    assert int(out['plan_exchanges']) >= 1                 # the library's message list really was the transport
