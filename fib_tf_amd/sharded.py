@@ -356,6 +356,9 @@ class ShardedStepper:
         return self.eng.launch_plan()
 
     def close(self):
+        if self.rccl_direct:
+            self.eng.st.comm_free()
+            self.rccl_direct = False
         if hasattr(self.eng, 'close'):
             self.eng.close()
 
@@ -454,6 +457,11 @@ def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
                          'frac': round(achieved / hbm_peak, 4), 'traffic': None,
                          'note': 'per GPU, whole tick incl. halo exchange (wall / ticks); kernel-only figure: N=1 line'},
         }
+    # orderly teardown: every rank drains its stream and releases the library's communicator before anyone leaves
+    st.sync()
+    dist.barrier()
+    if getattr(st, 'rccl_direct', False):
+        st.eng.st.comm_free()
     dist.barrier()
     dist.destroy_process_group()
     return out
