@@ -41,14 +41,23 @@ def main(out):
                   and torch.equal(slab[g:b], before[g:b]))
         eng.step(2)
         torch.cuda.synchronize()
-    # wrong usage is refused, not executed
+    # wrong usage is refused, not executed: outside an open tick; neighbours that do not match the ghost rows
     refused = 0
-    for bad in ((None, 0), (0, None)):
+    try:
+        eng.comm_exchange(0, 0)
+    except _lib.FibhipError:
+        refused += 1
+    with eng.stream_ctx():
+        eng.step(1)                                        # mid-cycle tick, then the exchange tick of the cycle
+        eng.step_edges()
         try:
-            eng.step_edges() if False else None
-            eng.comm_exchange(*bad)
+            eng.comm_exchange(None, 0)
         except _lib.FibhipError:
             refused += 1
+        eng.comm_exchange(0, 0)
+        eng.step_interior()
+        eng.step_commit()
+        torch.cuda.synchronize()
     np.save(out, np.array([ok, refused == 2]))
 
 
