@@ -9,16 +9,29 @@ whole grid (Fenton 10, fenton.py:133-138; BR 5; Courtemanche 1), i.e. one `sess.
 
 N = 1 (default): BASELINE.json configs[1] — Fenton 4v, 512x512, dt 0.1, diff 1.5, hole (256,256,30),
 S1 column, S2 'luq' at tick 210 — driven tick by tick exactly as `IonicModel.run()` drives it.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is sharded by row blocks
-(fib_tf_amd/sharded.py), halos travel as RCCL point-to-point; weak scaling: every rank owns a
-512-row x W block (`--rows-per-gpu`), W = `--size`.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and
-`cpu_baseline` (the oracle = CPU restatement of the reference, timed on this host's cores).
+N > 1: BASELINE.json configs[3] — Fenton 4v 4096x4096 split into N row blocks (fib_tf_amd/sharded.py),
+hole (2048,2048,240), halos as RCCL point-to-point; the grid is fixed, so the N > 1 lines are a strong-
+scaling series (`--scaling strong --size 512` = north_star's "512x512 at 1/2/4/8"; `--scaling weak` =
+`--rows-per-gpu` rows on every GPU).  One process per GPU.  Under a launcher (WORLD_SIZE set: `python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) this process IS one rank.  Without one,
+`python bench.py --gpus N` starts the N ranks itself as child processes (the parent makes no GPU call),
+relays rank 0's JSON line, and exits non-zero if a rank fails or the box has fewer than N devices.
+
+Timing protocol: untimed set-up ticks (code objects, RCCL channels, clocks), W warm-up ticks, then
+`--repeats` (3) timed regions of EXACTLY K ticks each, every one bracketed by a barrier + device synchronisation;
+per region the MAX over ranks, over regions the MEDIAN.  Prints ONE JSON line (rank 0) with `roofline`
+(dominant kernel, HIP-event timed on its own stream; + `issue` = the instruction-issue ceiling and `cache` = L2
+hit rate from the committed rocprofv3 counters), `cpu_baseline` (the oracle = CPU restatement of the reference,
+timed on this host's cores), `value_with_snapshots` (the reference driver's read-backs inside the timed region)
+and `exact` (the rounding-faithful arithmetic policy timed the same way).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,22 +41,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'traffic_r01.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# rocprofv3 --pmc passes of this command, condensed by tools/prof_summary.py (PMC cannot run inside the bench)
+COUNTERS_JSON = [os.path.join(ROOT, 'profiles', 'counters_r02.json'), os.path.join(ROOT, 'profiles', 'traffic_r01.json')]
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32; max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+CYC_VALU, CYC_TRANS = 2.0, 8.0   # issue cycles of a wave64 VALU / transcendental instruction on one SIMD (same guide)
 # algorithmic bytes per cell per sub-step: every state array read once + every updated
-# array written once, float32, + 4 B for the phase field
+# array written once, float32, + 4 B for the phase field.  Courtemanche: the fast tick reads 21 arrays and
+# writes 4 (100 B); the every-10th tick also assigns the other 17 (168 B); mean 106.8.
 ALGO_BYTES = {'fenton': 32, 'br': 64, 'court': 106.8}
+COURT_FAST_BYTES, COURT_SLOW_BYTES = 100.0, 168.0
 
 
-def make_model(args, height=None, device=0):
+def make_model(args, height=None, device=0, exact=None):
     from fib_tf_amd.fenton import Fenton4v
     from fib_tf_amd.br import BeelerReuter
     from fib_tf_amd.court import Courtemanche
     S = args.size
     H = height or S
     sc = S / 512.0
+    exact = args.exact if exact is None else exact
     base = {'width': S, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'timeline': False,
-            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not args.exact,
+            'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not exact,
             'halo_ticks': getattr(args, 'halo_ticks', 4)}
     if args.model == 'fenton':                        # fenton.py:156-171
         m = Fenton4v(dict(base, diff=1.5))
@@ -61,26 +80,42 @@ def make_model(args, height=None, device=0):
     return m, s2
 
 
-def cpu_baseline(args, seconds=12.0):
-    """the oracle (CPU restatement, OpenMP over all host cores) on a bounded sample of the SAME
-    workload: same grid, phase field and initial conditions, fewer sub-steps"""
+def cpu_baseline(args, height=None, seconds=12.0):
+    """the oracle (CPU restatement, OpenMP) on a bounded sample of the SAME workload: same grid, phase field and
+    initial conditions, fewer sub-steps.  Three figures: the default thread count (the GPU box's stated CPU share,
+    16), every core this process may use (affinity + cgroup quota), and one thread."""
     import oracle
     oracle.build()
-    m, _ = make_model_host(args)
-    slab, phi, run = m
-    run(slab, 20)                                     # page in + calibrate
+    slab, phi, run = make_model_host(args, height)
+    cells = slab.shape[1] * slab.shape[2]
+    threads = oracle.num_threads()
+    run(slab, 10)                                     # page in + calibrate
     t0 = time.perf_counter()
-    run(slab, 40)
-    per = (time.perf_counter() - t0) / 40
-    n = int(max(40, min(seconds / per, 200000)))
+    run(slab, 20)
+    per = (time.perf_counter() - t0) / 20
+    n = int(max(20, min(seconds / per, 200000)))
     t0 = time.perf_counter()
     run(slab, n)
     dt = time.perf_counter() - t0
-    cells = slab.shape[1] * slab.shape[2]
-    threads = oracle.num_threads()
+    out = {'value': round(cells * n / dt / 1e6, 2), 'unit': 'Mcell-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': '%d sub-steps of the same %dx%d %s workload (%.1f s), oracle/fib_oracle.c with OpenMP'
+                     % (n, slab.shape[1], slab.shape[2], args.model, dt)}
+    # every usable core (BASELINE.md 3: "all host cores"), about 5 s
+    allc = oracle.usable_cores()
+    if allc != threads:
+        oracle.set_threads(allc)
+        run(slab, 10)
+        na = int(max(20, min(5.0 / (per * threads / allc), 400000)))
+        t0 = time.perf_counter()
+        run(slab, na)
+        dta = time.perf_counter() - t0
+        out['value_all_cores'] = round(cells * na / dta / 1e6, 2)
+    else:
+        out['value_all_cores'] = out['value']
+    out['cores_all'] = allc
     # one-thread figure (a scalar port of the reference), about 3 s
     oracle.set_threads(1)
-    n1 = int(max(10, min(3.0 / (per * threads * 0.6), 20000)))
+    n1 = int(max(5, min(3.0 / (per * threads * 0.6), 20000)))
     t0 = time.perf_counter()
     run(slab, n1)
     dt1 = time.perf_counter() - t0
@@ -91,31 +126,30 @@ def cpu_baseline(args, seconds=12.0):
             model_name = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
     except OSError:
         pass
-    return {'value': round(cells * n / dt / 1e6, 2), 'unit': 'Mcell-steps/s', 'cores': threads,
-            'kind': 'port', 'sample': '%d sub-steps of the same %dx%d %s workload (%.1f s), oracle/fib_oracle.c '
-            'with OpenMP' % (n, slab.shape[1], slab.shape[2], args.model, dt),
-            'value_1thread': round(cells * n1 / dt1 / 1e6, 2), 'cpu_model': model_name,
-            'host_cpu_count': os.cpu_count(), 'omp_num_threads': os.environ.get('OMP_NUM_THREADS', 'unset')}
+    out.update({'value_1thread': round(cells * n1 / dt1 / 1e6, 2), 'cpu_model': model_name,
+                'host_cpu_count': os.cpu_count(), 'omp_num_threads': os.environ.get('OMP_NUM_THREADS', 'unset')})
+    return out
 
 
-def make_model_host(args):
+def make_model_host(args, height=None):
     """host-only construction of the benchmark workload for the oracle (no GPU calls)"""
     import oracle
     from fib_tf_amd.ionic import IonicModel
     S = args.size
+    H = height or S
     sc = S / 512.0
-    g = IonicModel({'width': S, 'height': S})
+    g = IonicModel({'width': S, 'height': H})
     if args.model == 'fenton':
-        g.add_hole_to_phase_field(256 * sc, S / 2.0, 30 * sc)
-        slab = np.zeros((4, S, S), np.float32)
+        g.add_hole_to_phase_field(256 * sc, H / 2.0, 30 * sc)
+        slab = np.zeros((4, H, S), np.float32)
         slab[1] = 1.0
         slab[2] = 1.0
         slab[0][:, 1] = 1.0
         run = lambda s, n: oracle.fenton_run(s, 0.1, 1.5, g.phase, n)
     elif args.model == 'br':
         from fib_tf_amd.br import BeelerReuter
-        g.add_hole_to_phase_field(150 * sc, 200 * sc, 40 * sc)
-        slab = np.empty((8, S, S), np.float32)
+        g.add_hole_to_phase_field(150 * sc, 200 * sc * H / S, 40 * sc)
+        slab = np.empty((8, H, S), np.float32)
         for i, v in enumerate((-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)):
             slab[i] = v
         slab[0][:, 1] = 10.0
@@ -124,18 +158,106 @@ def make_model_host(args):
         run = lambda s, n: oracle.br_run(s, 0.1, 0.809, g.phase, tbl, args.skip, max(1, n // 5))
     else:
         from fib_tf_amd.court import INITIAL
-        g.add_hole_to_phase_field(256 * sc, S / 2.0, 30 * sc)
-        g.add_hole_to_phase_field(256 * sc, S / 2.0, 250 * sc, neg=True)
-        slab = np.empty((21, S, S), np.float32)
+        g.add_hole_to_phase_field(256 * sc, H / 2.0, 30 * sc)
+        g.add_hole_to_phase_field(256 * sc, H / 2.0, 250 * sc, neg=True)
+        slab = np.empty((21, H, S), np.float32)
         for i, (_, v) in enumerate(INITIAL):
             slab[i] = v
         slab[0][:, :25] = 20.0
         run = lambda s, n: oracle.court_run(s, 0.1, 0.809, g.phase, True, 0, n)
-    return (slab, g.phase, run), None
+    return slab, g.phase, run
 
 
-def bench_single(args):
-    m, (loc, amp, s2_ms) = make_model(args, device=0)
+def counters_for(key):
+    """the committed rocprofv3 --pmc record of this kernel shape, or {}"""
+    for path in COUNTERS_JSON:
+        try:
+            rec = json.load(open(path)).get(key)
+        except (OSError, ValueError):
+            rec = None
+        if rec:
+            return dict(rec, source=os.path.relpath(path, ROOT))
+    return {}
+
+
+def roofline_extras(roof, key, us_per_launch):
+    """traffic / issue ceiling / cache hit rates of the dominant kernel from the committed counter passes"""
+    rec = counters_for(key)
+    roof['traffic'] = rec.get('hbm_bytes_per_launch_corrected')
+    valu, trans = rec.get('SQ_INSTS_VALU'), rec.get('SQ_INSTS_VALU_TRANS_F32')
+    if valu is not None:
+        # wave-instructions per launch over all waves; a SIMD issues a wave64 VALU instruction in 2 cycles and a
+        # transcendental in 8: the time the chip's 1024 SIMDs need just to ISSUE them, against the launch time
+        t = trans or 0.0
+        cycles = ((valu - t) * CYC_VALU + t * CYC_TRANS) / N_SIMD
+        us = cycles / (CLOCK_GHZ * 1e3)
+        roof['issue'] = {'bound': 'valu-issue', 'valu_wave_instr_per_launch': round(valu), 'trans_wave_instr_per_launch':
+                         None if trans is None else round(trans), 'salu_wave_instr_per_launch':
+                         None if rec.get('SQ_INSTS_SALU') is None else round(rec['SQ_INSTS_SALU']),
+                         'cycles_per_valu': CYC_VALU, 'cycles_per_trans': CYC_TRANS, 'simds': N_SIMD, 'clock_ghz': CLOCK_GHZ,
+                         'issue_us_per_launch': round(us, 3), 'frac': round(us / us_per_launch, 4),
+                         'note': 'fraction of the launch the SIMDs spend issuing vector instructions; this, not HBM, is '
+                                 'the ceiling once K sub-steps are fused (frac of the HBM figure can then exceed 1)'}
+    hit, miss = rec.get('TCC_HIT_sum'), rec.get('TCC_MISS_sum')
+    if hit is not None and miss is not None and hit + miss > 0:
+        roof['cache'] = {'l2_hit_rate': round(hit / (hit + miss), 4), 'TCC_HIT_sum': round(hit), 'TCC_MISS_sum': round(miss)}
+        for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_WRREQ_sum', 'TCC_EA0_WRREQ_DRAM_sum'):
+            if rec.get(k) is not None:
+                roof['cache'][k] = round(rec[k])
+        rd, rdd = rec.get('TCC_EA0_RDREQ_sum'), rec.get('TCC_EA0_RDREQ_DRAM_sum')
+        if rd and rdd is not None:
+            roof['cache']['infinity_cache_read_hit_rate'] = round(1.0 - rdd / rd, 4)
+    if rec:
+        roof['counters_source'] = '%s [%s], kernel %s' % (rec.get('source'), key, rec.get('kernel', '?'))
+    return roof
+
+
+def driver_loop(m, st, s2, court):
+    """IonicModel.run()'s loop body with the reference driver's side calls (court.py:612-617, fenton.py:181-183);
+    `snap` adds its read-backs (fenton.py:184-185: image() every 10 ms; court.py:618: the trend probe)"""
+    state = {'tick': 0}
+    ds = max(1, m.millisecond_to_step(10))
+
+    def advance(n, snap=False):
+        tick = state['tick']
+        for _ in range(n):
+            st.step(1)
+            if court and tick % 10 == 0:
+                st.step_slow()
+                if snap:
+                    m.fire_op('trend')
+            if tick == s2:
+                m.fire_op('s2')
+            if snap and tick % ds == 0:
+                m.image()
+            tick += 1
+        state['tick'] = tick
+    return advance
+
+
+def timed_regions(advance, sync, steps, repeats, barrier=None, snap=False):
+    """`repeats` regions of exactly `steps` ticks, each bracketed by barrier + device sync; wall seconds per region"""
+    walls = []
+    for _ in range(repeats):
+        sync()
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        advance(steps, snap)
+        sync()
+        if barrier:
+            barrier()
+        walls.append(time.perf_counter() - t0)
+    return walls
+
+
+def kernel_key(args, exact, H, W, fused, shard=False):
+    return '%s/%s/%dx%d/K%d%s' % (args.model, 'exact' if exact else 'fast', H, W, fused, '/shard' if shard else '')
+
+
+def measure_single(args, exact, with_extras):
+    """one model on device 0: (value, ms_per_tick, roofline dict, walls, snapshots value, model)"""
+    m, (loc, amp, s2_ms) = make_model(args, device=0, exact=exact)
     m.define()
     m.add_pace_op('s2', loc, amp)
     s2 = m.millisecond_to_step(s2_ms)
@@ -143,59 +265,71 @@ def bench_single(args):
     fused, per_tick = st.launch_plan()
     spt = m.dt_per_step
     court = args.model == 'court'
-    tick = 0
-
-    def advance(n):
-        nonlocal tick
-        for _ in range(n):                            # exactly IonicModel.run()'s loop body
-            st.step(1)
-            if court and tick % 10 == 0:              # court.py:615-617
-                st.step_slow()
-            if tick == s2:
-                m.fire_op('s2')
-            tick += 1
-
-    st.step(1)                                        # setup, not a warm-up step: loads the code object
+    advance = driver_loop(m, st, s2, court)
+    st.step(1)                                        # set-up, not a warm-up step: loads the code object
     st.sync()
-    tick = 1
+    advance(args.setup)                               # set-up: clocks and caches in their steady state
     advance(args.warmup)
-    st.sync()
-    t0 = time.perf_counter()
-    advance(args.steps)
-    st.sync()
-    wall = time.perf_counter() - t0
-
+    walls = timed_regions(advance, st.sync, args.steps, args.repeats)
+    wall = statistics.median(walls)
     cells = m.height * m.width
     value = cells * args.steps * spt / wall / 1e6
-    # dominant kernel, HIP events on the kernel's own stream, back-to-back launches
-    ms, launches = st.time_steps(max(50, min(args.steps, 500)))
-    us_per_launch = ms * 1000.0 / launches
+
+    # dominant kernel: HIP events on the kernel's own stream around the SAME tick mix (for Courtemanche that
+    # includes every 10th tick's fused fast+slow launch), back-to-back launches
+    nt = max(50, min(args.steps, 500))
+    if court:
+        nt = (nt + 9) // 10 * 10                      # whole fast/slow periods
+    st.sync()
+    st.time_begin()
+    advance(nt)
+    ms, launches = st.time_end()
+    us_per_launch = ms * 1000.0 / max(1, launches)
     abytes = ALGO_BYTES[args.model] + (4 if m.phase is not None else 0)
-    achieved = abytes * cells * fused / (us_per_launch * 1e-6) / 1e9
-    traffic = None
-    try:                                              # measured offline (PMC cannot run inside the bench)
-        key = '%s/%s/%dx%d/K%d' % (args.model, 'exact' if args.exact else 'fast', m.height, m.width, fused)
-        traffic = json.load(open(TRAFFIC_JSON)).get(key, {}).get('hbm_bytes_per_launch_corrected')
-    except (OSError, ValueError):
-        pass
+    per_launch_bytes = abytes * cells * spt * nt / max(1, launches)      # mean over the launches of the mix
+    achieved = per_launch_bytes / (us_per_launch * 1e-6) / 1e9
+    name = 'strip_kernel' if fused > 1 and args.model in ('fenton', 'br') else 'tick_kernel'
+    roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+            'kernel': '%s<%s, K=%d>' % (name, args.model, fused), 'us_per_launch': round(us_per_launch, 3),
+            'launches_timed': launches, 'ticks_timed': nt,
+            'algorithmic_bytes_per_launch': int(per_launch_bytes),
+            'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
+                    'one-step-per-pass implementation must move, K fused sub-steps move them once'}
+    if court:
+        roof['note'] += ('; Courtemanche: the timed mix is 9 fast ticks (%.0f B/cell) + 1 fused fast+slow tick '
+                         '(%.0f B/cell) per 10, bytes and time both of the mix' % (COURT_FAST_BYTES + 4, COURT_SLOW_BYTES + 4))
+    snaps = None
+    if with_extras:
+        roofline_extras(roof, kernel_key(args, exact, m.height, m.width, fused), us_per_launch)
+        ws = timed_regions(advance, st.sync, args.steps, 1, snap=True)
+        snaps = cells * args.steps * spt / ws[0] / 1e6
+    return value, wall * 1000.0 / args.steps, roof, walls, snaps, m
+
+
+def bench_single(args):
+    value, ms_tick, roof, walls, snaps, m = measure_single(args, args.exact, True)
+    st = m._stepper
+    fused, per_tick = st.launch_plan()
+    spt = m.dt_per_step
     out = {
         'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d' % (
             {'fenton': '4v', 'br': 'BR', 'court': 'Courtemanche'}[args.model], m.height, m.width),
         'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(wall * 1000.0 / args.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(ms_tick, 6), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %dx%d, dt=0.1 ms, phase-field hole, S1 + S2 pacing (BASELINE configs[%d]); '
                                '1 step = 1 run() tick = %d sub-steps' % (
                                    args.model, m.height, m.width, {'fenton': 1, 'br': 2, 'court': 4}[args.model], spt),
                    'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                    'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
-                   'parallelism': 'single device'},
-        'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                     'kernel': '%s<%s, K=%d>' % ('strip_kernel' if fused > 1 and args.model in ('fenton', 'br') else 'tick_kernel', args.model, fused), 'us_per_launch': round(us_per_launch, 3),
-                     'algorithmic_bytes_per_launch': int(abytes * cells * fused),
-                     'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
-                             'one-step-per-pass implementation must move, K fused sub-steps move them once'},
+                   'parallelism': 'single device', 'setup_ticks': args.setup + 1,
+                   'timing': 'median of %d regions of %d ticks' % (args.repeats, args.steps)},
+        'repeats': args.repeats, 'wall_ms_per_region': [round(w * 1e3, 4) for w in walls],
+        'roofline': roof,
+        'value_with_snapshots': None if snaps is None else round(snaps, 1),
+        'snapshots_note': 'same %d ticks with the reference driver\'s read-backs inside the timed region: image() (D2H of '
+                          'the potential) every 10 ms of simulated time (fenton.py:184-185)' % args.steps,
     }
     try:                                              # achievable-bandwidth yardstick, measured in this very run
         from fib_tf_amd import _lib
@@ -203,38 +337,253 @@ def bench_single(args):
     except Exception as e:                            # never lose the result line over the yardstick
         out['roofline']['copy_bandwidth_measured'] = None
         print('copy bandwidth not measured: %s' % e, file=sys.stderr)
+    if not args.exact and not args.no_exact_leg:      # the rounding-faithful policy, timed the same way
+        st.close()
+        ev, ems, eroof, ewalls, _, em = measure_single(args, True, False)
+        ek, _ = em._stepper.launch_plan()
+        out['exact'] = {'value': round(ev, 1), 'ms_per_step': round(ems, 6), 'arithmetic': 'exact (one float32 rounding '
+                        'per reference op, no FMA contraction: the policy the bit-level parity claims hold for)',
+                        'roofline_frac': eroof['frac'], 'us_per_launch': eroof['us_per_launch'],
+                        'fused_sub_steps_per_launch': ek}
+        em._stepper.close()
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_devices():
+    """HIP devices this process could open, WITHOUT opening one (the parent of the ranks must stay off the GPU)"""
+    import torch
+    return torch.cuda.device_count()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes, one per GPU, relay
+    rank 0's result line.  This process makes no GPU call and never re-executes itself."""
+    one_device = os.environ.get('FIBTF_ONE_DEVICE') == '1'      # rehearsal: several gloo ranks on ONE GPU
+    have = visible_devices()
+    need = 1 if one_device else args.gpus
+    if have < need:
+        print('bench.py: --gpus %d needs %d HIP device(s), this box has %d' % (args.gpus, need, have), file=sys.stderr)
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                    # drain rank 0's stdout while it runs (a full pipe would block it)
+    deadline = time.time() + args.spawn_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or all(c is not None for c in codes) or time.time() > deadline:
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 1
+                print('bench.py: a rank exited with code %d; stopping the others' % bad[0], file=sys.stderr)
+            elif time.time() > deadline and any(c is None for c in codes):
+                rc = 3
+                print('bench.py: ranks still running after %d s; stopping them' % args.spawn_timeout, file=sys.stderr)
+            break
+        time.sleep(0.2)
+    for p in procs:                                   # exactly the processes started above, nothing by pattern
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    reader.join(timeout=15)
+    out = ''.join(chunks)
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    if rc == 0 and not lines:
+        print('bench.py: rank 0 printed no result line', file=sys.stderr)
+        rc = 1
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+def bench_ranks(args):
+    """this process is ONE rank of `world` (started by torch.distributed.run or by spawn_ranks)"""
+    import torch
+    import torch.distributed as dist
+    from fib_tf_amd import _lib
+    from fib_tf_amd.sharded import init_from_env
+    rank, world, local = init_from_env()
+    strong = args.scaling == 'strong'
+    H = args.size if strong else args.rows_per_gpu * world
+    m, (loc, amp, s2_ms) = make_model(args, height=H, device=local)
+    m.define()
+    m.add_pace_op('s2', loc, amp)
+    s2 = m.millisecond_to_step(s2_ms)
+    st = m._stepper
+    spt = m.dt_per_step
+    court = args.model == 'court'
+    advance = driver_loop(m, st, s2, court)
+
+    # (a one-rank group — only ever used to rehearse this path on one GPU — has a plain Stepper: no ghost zone)
+    halo_ticks, ghost, halo_n = getattr(st, 'halo_ticks', 1), getattr(st, 'g', 0), getattr(st, 'halo_n', 0)
+    advance(2 * halo_ticks)                             # set-up, not warm-up: two full exchange cycles create
+    st.sync()                                           # the RCCL channels and load the code objects
+    advance(args.setup // halo_ticks * halo_ticks)      # set-up: clocks in their steady state
+    advance(args.warmup)
+
+    def sync():
+        st.sync()
+        torch.cuda.synchronize()
+
+    comm0 = getattr(st, 'comm_s', 0.0)
+    walls = timed_regions(advance, sync, args.steps, args.repeats, barrier=dist.barrier)
+    wt = torch.tensor(walls, dtype=torch.float64, device='cuda')
+    dist.all_reduce(wt, op=dist.ReduceOp.MAX)                       # per region: the slowest rank
+    walls = [float(x) for x in wt.tolist()]
+    wall = statistics.median(walls)
+    comm = torch.tensor([getattr(st, 'comm_s', 0.0) - comm0], dtype=torch.float64, device='cuda')
+    dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+    nranks = torch.tensor([1], dtype=torch.int32, device='cuda')
+    dist.all_reduce(nranks, op=dist.ReduceOp.SUM)                   # what the communicator itself counts
+    fused, per_tick = st.launch_plan()
+    backend = dist.get_backend()
+
+    # per-GPU kernel figure (rank 0): the same row block — owned + ghost rows, row offset, interleaved slab — as a
+    # stand-alone handle, ticks timed with HIP events on its stream: the block's kernels without any exchange
+    kern = None
+    if rank == 0 and hasattr(st, 'lh'):
+        probe = _lib.Stepper(m.MODEL_ID, st.lh, m.width, m.dt, m.diff, flags=m._flags() | _lib.ROW_INTERLEAVED, device=local,
+                             steps_per_tick=spt, global_height=H, row_offset=st.lo, ghost_top=st.gt, ghost_bottom=st.gb,
+                             library=m._library)
+        m._configure_stepper(probe)
+        if m.phase is not None:
+            probe.set_phase(np.ascontiguousarray(m.phase[st.lo:st.lo + st.lh]))
+        probe.set_state(-1, st.eng.get_state(-1))
+        probe.step(2 * halo_ticks)
+        probe.sync()
+        ms, launches = probe.time_steps(max(halo_ticks, 200 // halo_ticks * halo_ticks))
+        kern = (ms * 1000.0 / max(1, launches), launches, max(halo_ticks, 200 // halo_ticks * halo_ticks), probe.launch_plan()[0])
+        probe.close()
+
+    out = None
+    if rank == 0:
+        cells = H * m.width
+        value = cells * args.steps * spt / wall / 1e6
+        abytes = ALGO_BYTES[args.model] + (4 if m.phase is not None else 0)
+        us_tick = wall * 1e6 / args.steps
+        own = st.rows if hasattr(st, 'rows') else H
+        tick_achieved = abytes * own * m.width * spt / (us_tick * 1e-6) / 1e9
+        cfgi = 3 if (args.model == 'fenton' and strong and args.size == 4096) else None
+        roof = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'traffic': None,
+                'whole_tick': {'achieved': round(tick_achieved, 1), 'frac': round(tick_achieved / HBM_PEAK_GBS, 4),
+                               'us_per_tick': round(us_tick, 3),
+                               'note': 'rank 0\'s owned rows x algorithmic bytes / (wall / ticks): kernels + halo exchange'}}
+        if kern:
+            us_l, launches, nt, kf = kern
+            per_launch = abytes * own * m.width * spt * nt / max(1, launches)
+            ach = per_launch / (us_l * 1e-6) / 1e9
+            roof.update({'achieved': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'us_per_launch': round(us_l, 3),
+                         'kernel': '%s<%s, K=%d> on one rank\'s block (%d owned + %d ghost rows x %d)' % (
+                             'strip_kernel' if kf > 1 else 'tick_kernel', args.model, kf, own, st.lh - own, m.width),
+                         'algorithmic_bytes_per_launch': int(per_launch), 'launches_timed': launches,
+                         'note': 'per GPU: the block\'s kernels alone (HIP events, no exchange; ghost-row work is not '
+                                 'counted as useful bytes); whole_tick adds the halo exchange'})
+            roofline_extras(roof, kernel_key(args, args.exact, st.lh, m.width, kf, shard=True), us_l)
+        else:
+            roof.update({'achieved': roof['whole_tick']['achieved'], 'frac': roof['whole_tick']['frac']})
+        out = {
+            'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d over %d GPUs' % (
+                {'fenton': '4v', 'br': 'BR', 'court': 'Courtemanche'}[args.model], H, m.width, world),
+            'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(wall * 1000.0 / args.steps, 6), 'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d grid in %d row blocks of %d rows x %d cols%s, dt=0.1 ms, phase-field hole, '
+                                   'S1 + S2; 1 step = 1 tick = %d sub-steps'
+                                   % (args.model, H, m.width, world, H // world, m.width,
+                                      ' (BASELINE configs[3])' if cfgi == 3 else
+                                      (' (%s scaling of BASELINE configs[1] by rows)' % ('strong' if strong else 'weak')), spt),
+                       'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
+                       'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
+                       'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one point-to-point send/recv pair per '
+                                      'neighbour every %d ticks, %d arrays in one contiguous message, interior '
+                                      'overlapped on a second stream on tall blocks' % (world, ghost, halo_ticks, halo_ticks, halo_n),
+                       'halo_transport': getattr(st, 'halo_path', 'none'), 'backend': backend,
+                       'ranks_in_communicator': int(nranks.item()),
+                       'halo_wait_s_max_rank': round(float(comm.item()), 4), 'setup_ticks': 2 * halo_ticks + args.setup // halo_ticks * halo_ticks,
+                       'timing': 'median of %d regions of %d ticks; per region the max over ranks' % (args.repeats, args.steps)},
+            'repeats': args.repeats, 'wall_ms_per_region': [round(w * 1e3, 4) for w in walls],
+            'roofline': roof,
+        }
+    # orderly teardown: every rank drains its stream and releases the library's communicator before anyone leaves
+    st.sync()
+    dist.barrier()
+    if getattr(st, 'rccl_direct', False):
+        st.eng.st.comm_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    if out is not None and not args.no_cpu:             # rank 0, after the group is gone: the other ranks have left
+        out['cpu_baseline'] = cpu_baseline(args, height=H, seconds=8.0)
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5000, help='ticks timed (1 tick = dt_per_step sub-steps)')
+    ap.add_argument('--steps', type=int, default=5000, help='ticks timed per region (1 tick = dt_per_step sub-steps)')
     ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps ticks; the median is reported')
+    ap.add_argument('--setup', type=int, default=400, help='untimed set-up ticks before the warm-up (clocks, caches)')
     ap.add_argument('--model', default='fenton', choices=['fenton', 'br', 'court'])
-    ap.add_argument('--size', type=int, default=0, help='grid width (and height at N=1); default 512 (1024 court)')
+    ap.add_argument('--size', type=int, default=0, help='grid width (and height unless --scaling weak); default: 512 at '
+                                                        'N=1 (1024 court), 4096 at N>1 (512 with --scaling weak)')
     ap.add_argument('--rows-per-gpu', type=int, default=512)
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                    help='N>1: weak = rows-per-gpu rows on every GPU (default); strong = the fixed size x size grid '
-                         'split over the N GPUs (north_star\'s "512x512 at 1/2/4/8")')
+    ap.add_argument('--scaling', default=None, choices=['weak', 'strong'],
+                    help='N>1: strong (default) = the fixed size x size grid split over the N GPUs (BASELINE configs[3] at '
+                         'the default size 4096; --size 512 = north_star\'s "512x512 at 1/2/4/8"); weak = rows-per-gpu '
+                         'rows on every GPU')
     ap.add_argument('--exact', action='store_true', help="config['fast_math']=False: one rounding per reference op")
+    ap.add_argument('--no-exact-leg', action='store_true', help='N=1: skip the second, rounding-faithful measurement')
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--halo-ticks', type=int, default=4, help='N > 1: ticks between two halo exchanges (ghost zone depth)')
+    ap.add_argument('--spawn-timeout', type=int, default=1500, help='N > 1 without a launcher: seconds before the ranks are stopped')
+    ap.add_argument('--force-dist', action='store_true', help='run the rank path even in a one-rank group (rehearsal)')
     args = ap.parse_args()
+    env_world = os.environ.get('WORLD_SIZE')
+    if args.gpus < 1:
+        ap.error('--gpus must be at least 1')
+    if args.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(args))
+    world = int(env_world or '1')
+    if world != args.gpus:
+        print('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree' % (args.gpus, world),
+              file=sys.stderr)
+        sys.exit(2)
+    multi = world > 1 or args.force_dist
+    if args.scaling is None:
+        args.scaling = 'strong'
     if not args.size:
-        args.size = 1024 if args.model == 'court' else 512
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 or world > 1:
-        from fib_tf_amd.sharded import bench_sharded
-        out = bench_sharded(args, make_model, cpu_baseline, ALGO_BYTES, HBM_PEAK_GBS)
-        if out is None:
-            return
-    else:
-        out = bench_single(args)
+        args.size = (4096 if args.scaling == 'strong' else 512) if world > 1 else (1024 if args.model == 'court' else 512)
+    out = bench_ranks(args) if multi else bench_single(args)
+    if out is None:
+        return
     print(json.dumps(out))
 
 

@@ -1,51 +1,56 @@
 #!/usr/bin/env python3
-"""The reference's `fenton.py __main__` (fenton.py:155-187) against fib_tf_amd: identical driver code,
-only the import differs.  Writes cube.npy (100 frames of image()*phase) like the reference.
+"""One simulated second of spiral-wave re-entry in the four-variable atrial model on a 512 x 512 sheet with a
+circular obstacle: a planar wave is started from the left edge (S1, part of the initial state), a second stimulus
+in the upper-left quadrant 210 ms later breaks it, and the broken end curls around the obstacle.  Every 10 ms
+the potential is read back (masked by the phase field) into a [frames, H, W] array saved as cube.npy, the format
+`python -m fib_tf_amd.playcube` replays.  Drives fib_tf_amd through the IonicModel / define() / run() interface.
 
-    python examples/run_fenton.py [--frames DIR]     # --frames: also write PNG frames through the headless Screen
+    python examples/run_fenton.py [--size N] [--ms T] [--frames DIR]
+        --size N      sheet edge in cells (default 512; obstacle and quadrant scale with it)
+        --ms T        simulated milliseconds (default 1000)
+        --frames DIR  also write PNG frames through the headless Screen
 """
+import argparse
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fib_tf_amd.fenton import Fenton4v          # reference: from fenton import Fenton4v
-from fib_tf_amd.screen import Screen            # reference: from screen import Screen
+from fib_tf_amd.fenton import Fenton4v
+from fib_tf_amd.screen import Screen
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--ms', type=float, default=1000.0)
+    ap.add_argument('--frames', default=None)
+    args = ap.parse_args()
+    n = args.size
+    sheet = Fenton4v({'width': n, 'height': n, 'dt': 0.1, 'diff': 1.5, 'duration': args.ms, 'dt_per_plot': 10,
+                      'timeline': False, 'timeline_name': 'timeline_4v.json', 'save_graph': False})
+    sheet.add_hole_to_phase_field(n // 2, n // 2, 30 * n / 512.0)
+    sheet.define()
+    sheet.add_pace_op('s2', 'luq', 1.0)
+
+    screen = None
+    if args.frames:
+        os.makedirs(args.frames, exist_ok=True)
+        screen = Screen(n, n, 'four-variable model', png_pattern=os.path.join(args.frames, 'frame_%05d.png'))
+
+    second_stimulus = sheet.millisecond_to_step(210)
+    stride = sheet.millisecond_to_step(10)              # ticks between two recorded frames
+    frames = np.zeros([int(args.ms / 10.0), n, n], dtype=np.float32)
+    for tick in sheet.run(screen):
+        if tick == second_stimulus:
+            sheet.fire_op('s2')
+        if tick % stride == 0 and tick // stride < len(frames):
+            frames[tick // stride] = sheet.image() * sheet.phase
+    np.save('cube', frames)
+    cell_steps = n * n * sheet.samples * sheet.dt_per_step
+    print('%.0f Mcell-steps/s including the %d read-backs' % (cell_steps / sheet.elapsed / 1e6, len(frames)))
+
 
 if __name__ == '__main__':
-    config = {
-        'width': 512,           # screen width in pixels
-        'height': 512,          # screen height in pixels
-        'dt': 0.1,              # integration time step in ms
-        'dt_per_plot': 10,      # screen refresh interval in dt unit
-        'diff': 1.5,            # diffusion coefficient
-        'duration': 1000,       # simulation duration in ms
-        'timeline': False,      # flag to save a timeline (profiler)
-        'timeline_name': 'timeline_4v.json',
-        'save_graph': True      # accepted, ignored (there is no TF graph)
-    }
-    model = Fenton4v(config)
-    model.add_hole_to_phase_field(256, 256, 30)
-    model.define()
-    model.add_pace_op('s2', 'luq', 1.0)
-    im = None
-    if '--frames' in sys.argv:
-        d = sys.argv[sys.argv.index('--frames') + 1]
-        os.makedirs(d, exist_ok=True)
-        im = Screen(model.height, model.width, 'Fenton 4v Model', png_pattern=os.path.join(d, 'frame_%05d.png'))
-
-    s2 = model.millisecond_to_step(210)     # 210 ms
-    ds = model.millisecond_to_step(10)
-    n = int(model.duration / 10.0)
-    cube = np.zeros([n, model.height, model.width], dtype=np.float32)
-
-    for i in model.run(im):
-        if i == s2:
-            model.fire_op('s2')
-        if i % ds == 0:
-            cube[i // ds, :, :] = model.image() * model.phase
-
-    np.save('cube', cube)
-    print('%.0f Mcell-steps/s (including the %d image() read-backs)' % (
-        model.height * model.width * model.samples * model.dt_per_step / model.elapsed / 1e6, n))
+    main()

@@ -63,6 +63,8 @@ SYMBOLS = {
     'fibhip_probe': ([_h, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'fibhip_sync': ([_h], C.c_int),
     'fibhip_time_steps': ([_h, C.c_int, _fp, _ip], C.c_int),
+    'fibhip_time_begin': ([_h], C.c_int),
+    'fibhip_time_end': ([_h, _fp, _ip], C.c_int),
     'fibhip_step_edges': ([_h], C.c_int),
     'fibhip_step_interior': ([_h], C.c_int),
     'fibhip_step_commit': ([_h], C.c_int),
@@ -76,6 +78,7 @@ SYMBOLS = {
     'fibhip_halo_plan': ([_h, C.c_int, C.c_int, C.POINTER(HaloMsg), _ip], C.c_int),
     'fibhip_comm_open': ([C.c_char_p], C.c_int),
     'fibhip_comm_unique_id': ([C.c_char_p], C.c_int),
+    'fibhip_comm_check': ([_h, C.c_int, C.c_int], C.c_int),
     'fibhip_comm_init': ([_h, C.c_char_p, C.c_int, C.c_int], C.c_int),
     'fibhip_comm_exchange': ([_h, C.c_int, C.c_int], C.c_int),
     'fibhip_comm_free': ([_h], C.c_int),
@@ -287,6 +290,15 @@ class Stepper:
         self._ck(self._L.fibhip_time_steps(self._h, nticks, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def time_begin(self):
+        self._ck(self._L.fibhip_time_begin(self._h))
+
+    def time_end(self):
+        """(milliseconds, launches) since time_begin, by HIP events on the handle's stream"""
+        ms, n = C.c_float(), C.c_int()
+        self._ck(self._L.fibhip_time_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def step_edges(self):
         self._ck(self._L.fibhip_step_edges(self._h))
 
@@ -319,6 +331,10 @@ class Stepper:
         buf = C.create_string_buffer(128)
         self._ck(self._L.fibhip_comm_unique_id(buf))
         return buf.raw
+
+    def comm_check(self, rank, nranks):
+        """the local checks of comm_init (no collective): raises if this rank could not join"""
+        self._ck(self._L.fibhip_comm_check(self._h, rank, nranks))
 
     def comm_init(self, unique_id, rank, nranks, librccl_path=None):
         self._ck(self._L.fibhip_comm_open(librccl_path.encode() if librccl_path else None))

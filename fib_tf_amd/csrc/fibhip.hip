@@ -255,7 +255,7 @@ struct fibhip_ctx {
     std::vector<PlanItem> plan;
     hipEvent_t ev_main, ev_int, ev_t0, ev_t1;
     int phase_of_tick;      // 0 idle, 1 edges issued, 2 interior issued
-    long launches;
+    long launches, t_launches0;
     int own0, own1;         // owned local rows
     bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
     bool pending;           // fibhip_step's last tick has not been launched yet (see lazy_fusable)
@@ -688,7 +688,10 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
                                     (size_t)h->d.height, hipMemcpyHostToDevice, h->s0));
     }
     HIPCHK(hipStreamSynchronize(h->s0));
-    h->cpos = 0;                                  // the caller supplied fresh ghost rows too
+    // The whole slab restarts the exchange cycle: the caller supplied fresh ghost rows of every array.  ONE array
+    // does not: mid-cycle the other arrays' outer ghost rows are stale, so the cycle position stays and the rows
+    // of `var` that are still live at this position are the ones the caller's copy has to be right in.
+    if (var < 0) h->cpos = 0;
     return 0;
 }
 
@@ -1089,6 +1092,30 @@ extern "C" int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int 
     return 0;
 }
 
+// HIP-event bracket on the handle's stream around whatever the caller enqueues in between (ticks, 'slow' ops,
+// pacing): bench.py times the reference driver's real tick mix with it.
+extern "C" int fibhip_time_begin(fibhip_t h)
+{
+    NEED(h);
+    FLUSH(h);
+    h->t_launches0 = h->launches;
+    HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+    return 0;
+}
+
+extern "C" int fibhip_time_end(fibhip_t h, float *elapsed_ms, int *launches)
+{
+    NEED(h);
+    FLUSH(h);
+    HIPCHK(hipEventRecord(h->ev_t1, h->s0));
+    HIPCHK(hipEventSynchronize(h->ev_t1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (launches) *launches = (int)(h->launches - h->t_launches0);
+    return 0;
+}
+
 // IonicModel's building blocks as array ops on HOST arrays (copied through the device), for the
 // unit-level parity tests: op 0 enforce_boundary(a), 1 laplace(a [, phi]), 2 phase_field(pad(a), phi),
 // 3 rush_larsen(a=g, b=g_inf, c=tau, dt).
@@ -1224,14 +1251,28 @@ extern "C" int fibhip_comm_unique_id(char *out128)
     return 0;
 }
 
-extern "C" int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks)
+// everything fibhip_comm_init can refuse WITHOUT talking to another rank: callers run it on every rank and agree
+// on the outcome before any of them enters the collective ncclCommInitRank (a rank that failed alone would
+// leave the others blocked inside it)
+extern "C" int fibhip_comm_check(fibhip_t h, int rank, int nranks)
 {
-    NEED(h);
-    if (!id128 || rank < 0 || rank >= nranks) return fail(FIBHIP_EINVAL, "comm_init: bad argument");
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    if (rank < 0 || rank >= nranks) return fail(FIBHIP_EINVAL, "comm_init: bad argument");
     if (!g_rccl.lib) return fail(FIBHIP_EINVAL, "comm_init: call fibhip_comm_open first");
     if (h->comm) return fail(FIBHIP_EINVAL, "comm_init: this handle already has a communicator");
     if (!(h->d.flags & FIBHIP_ROW_INTERLEAVED))
         return fail(FIBHIP_EINVAL, "comm_init: the direct exchange needs the row-interleaved slab (one block per message)");
+    if ((rank > 0) != (h->d.ghost_top > 0) || (rank < nranks - 1) != (h->d.ghost_bottom > 0))
+        if (nranks > 1)
+            return fail(FIBHIP_EINVAL, "comm_init: rank %d of %d does not match the ghost rows of this block", rank, nranks);
+    return 0;
+}
+
+extern "C" int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks)
+{
+    NEED(h);
+    if (!id128) return fail(FIBHIP_EINVAL, "comm_init: bad argument");
+    if (int rc = fibhip_comm_check(h, rank, nranks)) return rc;
     FibNcclId id;
     memcpy(id.internal, id128, sizeof id.internal);
     void *comm = nullptr;

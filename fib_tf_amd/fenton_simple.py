@@ -98,3 +98,13 @@ class Fenton4vSimple:
         print('elapsed: %f sec' % self.elapsed)
         if im:
             im.wait()
+
+
+class Fenton4vJIT(Fenton4vSimple):
+    """the reference's `fenton_jit.py`: the same model with `solve` inside an XLA JIT scope (`fenton_jit.py:128-135`)
+    and another trace-file name.  Fusion is what the kernel does already, so only the name differs here."""
+
+    def __init__(self, props):
+        super().__init__(props)
+        if 'timeline_name' not in props:
+            self.timeline_name = 'timeline_jit.json'

@@ -150,12 +150,14 @@ class ShardedStepper:
         self.recv_down = mk() if self.down is not None else None
         self._op_cache = {}
         self.comm_s = 0.0
-        # Halo transport on RCCL: by default the library issues ncclSend/ncclRecv itself on the compute stream
-        # (include/fibhip.h fibhip_comm_*): one C call and one RCCL kernel per exchange, 92 us per 4-tick cycle
-        # against 133 us through torch's batch_isend_irecv (tools/exchange_tick_cost.py).  FIBTF_HALO=torch forces
-        # the torch path; any rank failing to set the direct path up sends ALL ranks back to it, collectively.
+        # Halo transport on RCCL.  Default: torch.distributed's batch_isend_irecv on the slab views (one contiguous
+        # [g, nvar, width] block each way).  FIBTF_HALO=direct (opt-in): the library issues the grouped
+        # ncclSend/ncclRecv itself on the compute stream (include/fibhip.h fibhip_comm_*): one C call and one RCCL
+        # kernel per exchange, 92 us per 4-tick cycle against 133 us through torch on one GPU talking to itself
+        # (tools/exchange_tick_cost.py) — opt-in because two real ranks have not exchanged through it on hardware
+        # yet.  Any rank failing to set the direct path up sends ALL ranks back to the torch path, collectively.
         self.rccl_direct = False
-        if (not self.staged and engine_factory is None and os.environ.get('FIBTF_HALO', 'direct') == 'direct'
+        if (not self.staged and engine_factory is None and os.environ.get('FIBTF_HALO', 'torch') == 'direct'
                 and (self.world > 1 or os.environ.get('FIBTF_HALO_SELFTEST') == '1')):    # (self-test: one-rank group)
             self.rccl_direct = self._setup_direct(group)
         self.halo_path = 'library ncclSend/ncclRecv on the compute stream' if self.rccl_direct else (
@@ -168,11 +170,15 @@ class ShardedStepper:
         return bool(int(t.item()))
 
     def _setup_direct(self, group):
+        """communicator for the library-issued exchange.  Everything that can fail on ONE rank (dlopen/dlsym of
+        librccl, the handle's flags, ghost rows vs neighbours) is checked locally and agreed on BEFORE any rank
+        enters the collective ncclCommInitRank: a rank that raised alone would leave the others blocked in it."""
         torch, dist = self.torch, self.dist
         path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
         uid, ok = None, True
-        try:                                                # bind RCCL; rank 0 draws the communicator id
+        try:                                                # bind RCCL; local checks; rank 0 draws the communicator id
             self.eng.st.comm_open(path)
+            self.eng.st.comm_check(self.rank, self.world)
             if self.rank == 0:
                 uid = self.eng.st.comm_unique_id(path)
         except Exception as e:                              # noqa: BLE001  (any failure = use the other transport)
@@ -182,7 +188,7 @@ class ShardedStepper:
             return False
         box = [uid if self.rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        try:
+        try:                                                # collective from here on: only RCCL itself can fail now
             self.eng.st.comm_init(box[0], self.rank, self.world, path)
         except Exception as e:                              # noqa: BLE001
             ok = False
@@ -384,84 +390,3 @@ def init_from_env():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
-
-
-def bench_sharded(args, make_model, cpu_baseline, algo_bytes, hbm_peak):
-    """bench.py --gpus N: weak scaling, every rank owns `rows_per_gpu` rows of a (rows_per_gpu*N) x size grid"""
-    import torch
-    import torch.distributed as dist
-    rank, world, local = init_from_env()
-    strong = getattr(args, 'scaling', 'weak') == 'strong'
-    H = args.size if strong else args.rows_per_gpu * world
-    m, (loc, amp, s2_ms) = make_model(args, height=H, device=local)
-    m.define()
-    m.add_pace_op('s2', loc, amp)
-    s2 = m.millisecond_to_step(s2_ms)
-    st = m._stepper
-    spt = m.dt_per_step
-    court = args.model == 'court'
-    tick = 0
-
-    def advance(n):
-        nonlocal tick
-        for _ in range(n):
-            st.step(1)
-            if court and tick % 10 == 0:
-                st.step_slow()
-            if tick == s2:
-                m.fire_op('s2')
-            tick += 1
-
-    # (a one-rank group — only ever used to rehearse this path on one GPU — has a plain Stepper: no ghost zone)
-    halo_ticks, ghost, halo_n = getattr(st, 'halo_ticks', 1), getattr(st, 'g', 0), getattr(st, 'halo_n', 0)
-    advance(halo_ticks)                                 # setup, not warm-up: one full exchange cycle creates
-    st.sync()                                           # the RCCL channels and loads the code objects
-    advance(args.warmup)
-    st.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    advance(args.steps)
-    st.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    wall = float(wall.item())
-    comm = torch.tensor([getattr(st, 'comm_s', 0.0)], dtype=torch.float64, device='cuda')
-    dist.all_reduce(comm, op=dist.ReduceOp.MAX)
-    fused, per_tick = st.launch_plan()
-    out = None
-    if rank == 0:
-        cells = H * m.width
-        value = cells * args.steps * spt / wall / 1e6
-        abytes = algo_bytes[args.model] + (4 if m.phase is not None else 0)
-        us_tick = wall * 1e6 / args.steps
-        achieved = abytes * (cells / world) * spt / (us_tick * 1e-6) / 1e9
-        out = {
-            'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d over %d GPUs' % (
-                args.model, H, m.width, world),
-            'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(wall * 1000.0 / args.steps, 6), 'higher_is_better': True,
-            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s %dx%d grid = %d rows x %d cols per GPU (%s scaling of BASELINE configs[1] by '
-                                   'rows), dt=0.1 ms, phase-field hole, S1 + S2; 1 step = 1 tick = %d sub-steps'
-                                   % (args.model, H, m.width, H // world, m.width, 'strong' if strong else 'weak', spt),
-                       'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
-                       'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one RCCL send/recv pair per '
-                                      'neighbour every %d ticks, %d arrays in one contiguous message, interior '
-                                      'overlapped on a second stream; transport: %s' % (world, ghost, halo_ticks, halo_ticks, halo_n,
-                                                                                       getattr(st, 'halo_path', 'none')),
-                       'halo_wait_s_max_rank': round(float(comm.item()), 4)},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': hbm_peak, 'unit': 'GB/s',
-                         'frac': round(achieved / hbm_peak, 4), 'traffic': None,
-                         'note': 'per GPU, whole tick incl. halo exchange (wall / ticks); kernel-only figure: N=1 line'},
-        }
-    # orderly teardown: every rank drains its stream and releases the library's communicator before anyone leaves
-    st.sync()
-    dist.barrier()
-    if getattr(st, 'rccl_direct', False):
-        st.eng.st.comm_free()
-    dist.barrier()
-    dist.destroy_process_group()
-    return out

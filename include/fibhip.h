@@ -103,7 +103,8 @@ int fibhip_destroy(fibhip_t h);
  * precede the first step.  NULL removes the phase field.                                               */
 int fibhip_set_phase(fibhip_t h, const float *phi);
 
-/* == tf.Variable(init) / define(state=...) (court.py:87-89).  var = -1: whole slab.                      */
+/* == tf.Variable(init) / define(state=...) (court.py:87-89).  var = -1: whole slab (restarts a row block's
+ * exchange cycle: the ghost rows come with it); var >= 0: one array, the cycle position is kept.          */
 int fibhip_set_state(fibhip_t h, int var, const float *src);
 
 /* == Variable.eval() (fenton.py:152-153, ionic.py:226-229).  Blocks until preceding ticks are done.     */
@@ -138,6 +139,10 @@ int fibhip_sync(fibhip_t h);
 /* Runs `nticks` ticks bracketed by HIP events on the handle's stream and returns the elapsed
  * milliseconds and the number of kernel launches in between (for the roofline line of bench.py).        */
 int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int *launches);
+/* The same bracket around whatever the caller enqueues between the two calls (ticks, 'slow' ops, pacing):
+ * the real tick mix of a reference driver loop (court.py:612-617) timed on the kernels' own stream.      */
+int fibhip_time_begin(fibhip_t h);
+int fibhip_time_end(fibhip_t h, float *elapsed_ms, int *launches);
 
 /* ---- row-block decomposition plumbing (multi-GPU; the halo exchange itself is the caller's RCCL) ----
  * One tick = step_edges (the tiles that produce the rows a neighbour needs; main stream) +
@@ -176,6 +181,8 @@ int fibhip_unit_op(int device, int op, int height, int width, const float *a, co
  * library.  RCCL is bound with dlopen: pass the path of the librccl the process uses (NULL if it is already loaded).
  *   fibhip_comm_open       once per process
  *   fibhip_comm_unique_id  on one rank; the caller broadcasts the 128 bytes
+ *   fibhip_comm_check      every local reason fibhip_comm_init could refuse, without the collective: run it on every
+ *                          rank and agree on the outcome BEFORE any rank enters fibhip_comm_init
  *   fibhip_comm_init       collective: every rank of the group, same id
  *   fibhip_comm_exchange   on an exchange tick (fibhip_halo_due), between step_edges and step_commit; -1 = no
  *                          neighbour on that side.  Needs FIBHIP_ROW_INTERLEAVED (one block per message).         */
@@ -190,6 +197,7 @@ typedef struct fibhip_halo_msg {
 int fibhip_halo_plan(fibhip_t h, int up_rank, int down_rank, fibhip_halo_msg *out4, int *slab_index);
 int fibhip_comm_open(const char *librccl_path);
 int fibhip_comm_unique_id(char *out128);
+int fibhip_comm_check(fibhip_t h, int rank, int nranks);   /* the local (non-collective) checks of comm_init */
 int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks);
 int fibhip_comm_exchange(fibhip_t h, int up_rank, int down_rank);
 int fibhip_comm_free(fibhip_t h);

@@ -218,9 +218,8 @@ def fenton_simple_run(slab, dt, diff, nsteps):
     return slab
 
 
-def host_cores():
-    """cores this process may actually use: affinity mask, cgroup quota, and the GPU box's stated
-    CPU share (16 per GPU) — OpenMP's default of one thread per visible core oversubscribes there"""
+def usable_cores():
+    """every core this process may use: affinity mask and cgroup CPU quota, no further cap"""
     n = len(os.sched_getaffinity(0))
     try:
         with open('/sys/fs/cgroup/cpu.max') as f:
@@ -229,6 +228,13 @@ def host_cores():
                 n = min(n, max(1, int(int(q) / int(p))))
     except (OSError, ValueError):
         pass
+    return max(1, n)
+
+
+def host_cores():
+    """default thread count: usable_cores() capped at the GPU box's stated CPU share (16 per GPU) —
+    OpenMP's default of one thread per visible core oversubscribes there"""
+    n = usable_cores()
     cap = int(os.environ.get('FIBTF_ORACLE_THREADS', '16'))
     return max(1, min(n, cap))
 

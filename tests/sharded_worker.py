@@ -41,7 +41,11 @@ def run_case(rank, world, port, case, outdir):
         m.add_pace_op('s2', 'luq', case['amp'])
         m.duration = ticks * m.dt_per_step * m.dt + 1e-9
         trend = []
+        poke = case.get('poke')                          # (tick, var): rewrite ONE array in mid-cycle, on every rank
         for i in m.run():
+            if poke and i == poke[0]:
+                name = m.VAR_NAMES[poke[1]]
+                m._stepper.set_state(poke[1], m._State[name].eval() * np.float32(0.5) + np.float32(0.125))
             if slow_trend and i % 10 == 0:
                 m.fire_op('slow')
                 m.fire_op('trend')

@@ -764,7 +764,7 @@ def test_fenton_simple_trajectory(gpu_lib, golden, policy, tmp_path, capsys):
 def test_fenton_jit_with_screen(gpu_lib, tmp_path):
     """run(im): a frame of the RAW potential after every dt_per_plot-th step (fenton_simple.py:195-197); the class
     of fenton_jit.py is the same model"""
-    from fib_tf_amd.fenton_jit import Fenton4vJIT
+    from fib_tf_amd.fenton_simple import Fenton4vJIT
     from fib_tf_amd.screen import Screen
     m = Fenton4vJIT({'width': 64, 'height': 48, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 1.5, 'samples': 100,
                      's2_time': 5.0, 'timeline_name': str(tmp_path / 't.json')})

@@ -34,6 +34,13 @@ CASES = [
     (4, {'model': 'fenton', 'H': 230, 'W': 70, 'diff': 1.5, 'hole': (30, 110, 9), 'ticks': 9, 's2': 4, 'amp': 1.0}),
     (4, {'model': 'br', 'H': 160, 'W': 64, 'diff': 0.809, 'hole': (30, 80, 8), 'ticks': 7, 's2': 3, 'amp': 10.0,
          'cheby': True, 'skip': False, 'halo_ticks': 2}),
+    # the width of BASELINE configs[3] (4096 columns: 76-93 tiles per tile row, the edge-strip / interior split really
+    # splits), four ranks, the default 4-tick ghost zone
+    (4, {'model': 'fenton', 'H': 212, 'W': 4096, 'diff': 1.5, 'hole': (2048, 106, 30), 'ticks': 6, 's2': 2, 'amp': 1.0,
+         'halo_ticks': 4}),
+    # ONE array rewritten through set_state in the middle of an exchange cycle
+    (3, {'model': 'fenton', 'H': 150, 'W': 96, 'diff': 1.5, 'hole': (40, 70, 9), 'ticks': 11, 's2': 8, 'amp': 1.0,
+         'halo_ticks': 4, 'poke': (5, 0)}),
     # traced model files (tests/models/): the generated library behind the same row-block driver
     (2, {'model': 'ap', 'H': 128, 'W': 80, 'diff': 1.0, 'hole': (30, 60, 8), 'ticks': 11, 's2': 4, 'amp': 1.0}),
     (3, {'model': 'gated', 'H': 90, 'W': 64, 'diff': 2.0, 'hole': (30, 40, 6), 'ticks': 31, 's2': 14, 'amp': 10.0,
@@ -59,6 +66,9 @@ def single(case):
     m.duration = case['ticks'] * m.dt_per_step * m.dt + 1e-9
     trend = []
     for i in m.run():
+        if case.get('poke') and i == case['poke'][0]:
+            v = case['poke'][1]
+            m._stepper.set_state(v, m._State[m.VAR_NAMES[v]].eval() * np.float32(0.5) + np.float32(0.125))
         if case['model'] in ('court', 'gated') and i % 10 == 0:
             m.fire_op('slow')
             m.fire_op('trend')
@@ -69,7 +79,7 @@ def single(case):
 
 
 @pytest.mark.parametrize('world,case', CASES,
-                         ids=['%s-x%d-h%s' % (c['model'], w, c.get('halo_ticks', 'd')) for w, c in CASES])
+                         ids=['%s-x%d-h%s-%dx%d' % (c['model'], w, c.get('halo_ticks', 'd'), c['H'], c['W']) for w, c in CASES])
 @pytest.mark.parametrize('split', ['auto', 'split'])
 def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split, monkeypatch):
     """split: force the two-stream edge-strips / interior launch on every exchange tick (the library only
@@ -99,22 +109,47 @@ def test_rccl_self_exchange_on_slab_views(gpu_lib, tmp_path):
     assert ok.all(), ok
 
 
-def test_bench_sharded_on_rccl_backend_single_rank(gpu_lib):
-    """bench.py's multi-rank branch on the real backend with a one-rank group: process-group init with device_id,
-    barriers, the MAX all-reduce of the timing, the result line (what two RCCL ranks would add is only the halo
-    messages themselves, covered by the self-exchange test above)"""
+def _bench(args, env_extra, timeout=600):
     import json
     import subprocess
     from test_sharded_cpu import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
-    env.pop('FIBTF_DIST_BACKEND', None)
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '200', '--warmup', '20'],
-                       capture_output=True, text=True, timeout=300, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FIBTF_DIST_BACKEND', 'FIBTF_ONE_DEVICE')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_rank_path_on_rccl_backend_single_rank(gpu_lib):
+    """bench.py's rank path on the real backend with a one-rank group (--force-dist): process-group init with
+    device_id, barriers, the MAX all-reduce of the timing, the result line (what two RCCL ranks would add is only the
+    halo messages themselves, covered by the self-exchange test above)"""
+    r, line = _bench(['--gpus', '1', '--force-dist', '--steps', '100', '--warmup', '10', '--setup', '20', '--no-cpu'],
+                     {'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'})
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 1 and line['value'] > 1000 and line['scaling'] == 'weak'
+    assert line['n_gpus'] == 1 and line['value'] > 1000 and line['config']['backend'] == 'nccl'
+    assert line['config']['ranks_in_communicator'] == 1 and len(line['wall_ms_per_region']) == 3
+
+
+def test_bench_more_gpus_than_devices_fails_loudly(gpu_lib):
+    """`python bench.py --gpus 2` on the one-GPU box: no result line, a non-zero exit and the reason"""
+    r, line = _bench(['--gpus', '2', '--steps', '10', '--warmup', '2'], {})
+    assert r.returncode != 0 and line is None
+    assert 'needs 2 HIP device' in r.stderr
+
+
+def test_bench_spawns_its_ranks(gpu_lib):
+    """`python bench.py --gpus 2` without a launcher starts two child ranks and relays rank 0's line.  The box has one
+    GPU, so the ranks share it and talk through gloo (FIBTF_ONE_DEVICE / FIBTF_DIST_BACKEND: rehearsal switches);
+    spawning, rendezvous, the timed regions, the kernel probe and the teardown are the production code."""
+    r, line = _bench(['--gpus', '2', '--size', '512', '--steps', '40', '--warmup', '8', '--setup', '16', '--no-cpu'],
+                     {'FIBTF_ONE_DEVICE': '1', 'FIBTF_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['ranks_in_communicator'] == 2
+    assert line['value'] > 1000 and line['roofline']['us_per_launch'] > 0 and line['roofline']['whole_tick']['us_per_tick'] > 0
 
 
 def test_direct_rccl_exchange_self(gpu_lib, tmp_path):

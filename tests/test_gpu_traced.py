@@ -56,6 +56,81 @@ def test_traced_model_matches_graph_interpreter(gpu_lib, name, H, W, hole, ticks
     del ctypes
 
 
+def _golden_init(f, names):
+    return np.stack([f['init_' + n] for n in names])
+
+
+def _close(got, want, tol, what, scale=None):
+    s = scale if scale is not None else max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= tol * s, '%s: max|d| %.3e > %.1e*%g' % (what, err, tol, s)
+
+
+@pytest.mark.parametrize('fixture', ['fenton_traj64', 'fenton_traj_ragged'])
+def test_generated_four_variable_equals_handwritten(gpu_lib, golden, fixture):
+    """tests/models/four_variable.py (our own model file in the reference's style) -> tracer -> generated kernel,
+    against (a) the golden trajectory the reference's own fenton.py produced and (b) the hand-written Fenton
+    kernel under the rounding-faithful policy: BITWISE — generated and hand-written code state the same graph with
+    one float32 rounding per node"""
+    from fib_tf_amd import _lib
+    f = golden(fixture)
+    names = ('U', 'V', 'W', 'S')
+    init = _golden_init(f, names)
+    _, H, W = init.shape
+    phase = f['phase'] if f['phase'].size else None
+    for fast, tol20 in ((False, 2e-5), (True, 2e-4)):
+        m = make_model('fv', H, W, fast_math=fast, diff=float(f['diff']))
+        m.phase = phase
+        m.define()
+        assert m.VAR_NAMES == names and m._stepper.launch_plan() == (10, 1)
+        m._stepper.set_state(-1, init)
+        nat = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, float(f['diff']), flags=_lib.FAST if fast else 0)
+        if phase is not None:
+            nat.set_phase(phase)
+        nat.set_state(-1, init)
+        t0 = 0
+        for t in [int(x) for x in f['snap_ticks']]:
+            if fast and t > 20:
+                break
+            m._stepper.step(t - t0)
+            nat.step(t - t0)
+            t0 = t
+            got = m._stepper.get_state(-1)
+            for i, n in enumerate(names):
+                _close(got[i], f['%s_t%d' % (n, t)], tol20 if t <= 20 else 3e-4, 'fv %s t%d' % (n, t), 1.0)
+            if not fast:
+                assert np.array_equal(got, nat.get_state(-1)), 'generated vs hand-written kernel differ at tick %d' % t
+
+
+def test_generated_eight_variable_vs_handwritten(gpu_lib, golden):
+    """tests/models/eight_variable.py -> generated kernel, against the golden trajectory of the reference's br.py
+    (direct gates) and the hand-written Beeler-Reuter kernel.  The hand-written kernel folds a few constants
+    differently (the exp(0*x) rows of the rate table), so equality with it is to rounding, not bitwise."""
+    from fib_tf_amd import _lib
+    f = golden('br_traj64_direct')
+    names = ('V', 'C', 'M', 'H', 'J', 'D', 'F', 'XI')
+    init = _golden_init(f, names)
+    _, H, W = init.shape
+    m = make_model('ev', H, W, fast_math=False, diff=float(f['diff']))
+    m.phase = f['phase']
+    m.define()
+    assert m.VAR_NAMES == names and m._stepper.launch_plan() == (5, 1)
+    m._stepper.set_state(-1, init)
+    nat = _lib.Stepper(_lib.BR, H, W, 0.1, float(f['diff']))
+    nat.set_phase(f['phase'])
+    nat.set_state(-1, init)
+    scales = {'V': 120.0, 'C': 1e-4}
+    t0 = 0
+    for t in [int(x) for x in f['snap_ticks']]:
+        m._stepper.step(t - t0)
+        nat.step(t - t0)
+        t0 = t
+        got, hand = m._stepper.get_state(-1), nat.get_state(-1)
+        for i, n in enumerate(names):
+            _close(got[i], f['%s_t%d' % (n, t)], 3e-5, 'ev %s t%d' % (n, t), scales.get(n, 1.0))
+            _close(got[i], hand[i], 3e-5, 'ev vs hand-written %s t%d' % (n, t), scales.get(n, 1.0))
+
+
 @pytest.mark.parametrize('name', ['ap', 'mrfhn'])
 @pytest.mark.parametrize('policy', ['exact', 'fast'])
 def test_fusion_depth_does_not_change_a_bit(gpu_lib, name, policy, monkeypatch):

@@ -52,6 +52,9 @@ def single_domain(case, orc):
         s[0][:, 1] = 1.0
         for i in range(case['ticks']):
             orc.fenton_run(s, 0.1, case['diff'], g.phase, 10)
+            if case.get('poke') and i == case['poke'][0]:
+                v = case['poke'][1]
+                s[v] = s[v] * np.float32(0.5) + np.float32(0.125)
             if i == case['s2']:
                 s[0] = orc.pace(s[0], *rect, case['amp'], 0.0)
         return s, None
@@ -102,11 +105,22 @@ CASES = [
          'halo_ticks': 2}),
     (5, {'model': 'br', 'H': 73, 'W': 21, 'diff': 0.809, 'hole': (10, 36, 4), 'ticks': 6, 's2': 2, 'amp': 10.0,
          'cheby': True, 'skip': False, 'halo_ticks': 2}),
+    # the 8-rank geometry of BASELINE configs[3] (4096 rows over 8 GPUs), scaled down: uneven blocks, six interior
+    # ranks, an exchange every tick and the default 4-tick ghost zone (tick count not a multiple of the cycle)
+    (8, {'model': 'fenton', 'H': 93, 'W': 24, 'diff': 1.5, 'hole': (12, 46, 5), 'ticks': 5, 's2': 2, 'amp': 1.0,
+         'halo_ticks': 1}),
+    (8, {'model': 'fenton', 'H': 331, 'W': 24, 'diff': 1.5, 'hole': (12, 160, 6), 'ticks': 10, 's2': 3, 'amp': 1.0,
+         'halo_ticks': 4}),
+    # ONE array rewritten through set_state in the middle of an exchange cycle (the other arrays' outer ghost rows
+    # are stale at that point: the cycle position must survive the call)
+    (3, {'model': 'fenton', 'H': 150, 'W': 28, 'diff': 1.5, 'hole': (14, 70, 5), 'ticks': 11, 's2': 8, 'amp': 1.0,
+         'halo_ticks': 4, 'poke': (5, 0)}),
 ]
 
 
 @pytest.mark.parametrize('world,case', CASES,
-                         ids=['%s-x%d-h%s' % (c['model'], w, c.get('halo_ticks', 'd')) for w, c in CASES])
+                         ids=['%s-x%d-h%s%s' % (c['model'], w, c.get('halo_ticks', 'd'), '-poke' if c.get('poke') else '')
+                              for w, c in CASES])
 def test_sharded_equals_single_domain(world, case, tmp_path, orc):
     out = launch(world, case, tmp_path)
     want, trend = single_domain(case, orc)
@@ -114,6 +128,21 @@ def test_sharded_equals_single_domain(world, case, tmp_path, orc):
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
     if trend is not None:
         assert np.array_equal(out['trend'], trend)
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself; on a box with fewer devices (this
+    container has none) it must fail loudly instead of printing a one-GPU line"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FIBTF_ONE_DEVICE')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'needs 2 HIP device' in r.stderr and '{' not in r.stdout
+    # under a launcher, --gpus and WORLD_SIZE must agree
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+                       timeout=300, env=dict(env, WORLD_SIZE='1', RANK='0'))
+    assert r.returncode != 0 and 'must agree' in r.stderr
 
 
 def test_row_blocks():

@@ -137,6 +137,21 @@ def test_reference_court_file_traced(ref_modules, golden):
     assert mode is None and len(host) == 2
 
 
+def test_reference_files_generate_compilable_source(ref_modules, tmp_path):
+    """compile-only: the HIP source generated from the reference's unchanged fenton.py and br.py builds for gfx950
+    (hipcc cross-compiles here).  The binaries stay in the test's temporary directory: nothing derived from the
+    reference leaves this container."""
+    from fib_tf_amd import _lib
+    for mod, cls, over in (('fenton', 'Fenton4v', {}), ('br', 'BeelerReuter', {'cheby': True})):
+        m = getattr(ref_modules[mod], cls)(cfg(32, 32, 1.0, **over))
+        m.define()
+        inc = tmp_path / (mod + '.inc')
+        inc.write_text(m._analyze()['source'])
+        so = tmp_path / (mod + '.so')
+        _lib.build_custom(str(inc), str(so))
+        assert so.stat().st_size > 10000
+
+
 # ---------------------------------------------------------------------------------------------------------
 # (2) no reference tree needed: tfgraph semantics, tracer structure and error behaviour on tests/models/
 # ---------------------------------------------------------------------------------------------------------
@@ -170,6 +185,30 @@ def test_tfgraph_scalar_semantics():
     g = tf.group(x.assign(x + 1), tf.group(tf.assign(x, x * 2)), None)
     assert len(g) == 2
     assert np.array_equal(x.eval(), np.zeros((4, 4), np.float32))               # before compile: the initial value
+
+
+@pytest.mark.parametrize('name,fixture,ticks,tol,scales', [
+    ('fv', 'fenton_traj64', [1, 2, 10, 20], 1e-6, None),
+    ('ev', 'br_traj64_direct', [1, 4, 20], 2e-6, {'V': 120.0, 'C': 1e-4})])
+def test_own_model_files_reproduce_reference_golden(clean_modules, golden, name, fixture, ticks, tol, scales):
+    """tests/models/four_variable.py and eight_variable.py (our own transcriptions of the two published models)
+    -> graph -> interpreter reproduce the golden trajectories generated from the reference's own files"""
+    sys.path.insert(0, HERE)
+    from traced_cases import make_model
+    from oracle.graph_eval import Interpreter
+    f = golden(fixture)
+    H, W = f['phase'].shape
+    m = make_model(name, H, W, diff=float(f['diff']))
+    m.phase = f['phase']
+    m.define()
+    c = m._analyze()
+    it = Interpreter(c, m.phase)
+    st = state_of(f, m.VAR_NAMES)
+    t0 = 0
+    for t in ticks:
+        st = it.tick(st, t - t0)
+        t0 = t
+        check(st, f, m.VAR_NAMES, t, tol, scales)
 
 
 @pytest.mark.parametrize('name,spt,kinds', [('ap', 10, 1), ('ms', 5, 1), ('gated', 1, 1), ('mrfhn', 4, 2)])

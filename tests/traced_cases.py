@@ -14,6 +14,9 @@ MODELS = {
     'ms': ('mitchell_schaeffer', 'MitchellSchaeffer', False, 0.1, 1.0, 0.9),
     'gated': ('gated', 'Gated', True, 0.02, 2.0, 10.0),
     'mrfhn': ('multirate', 'MultirateFHN', True, 0.1, 1.0, 1.5),
+    # our own transcriptions of the two published models the hand-written kernels implement: generated vs hand-written
+    'fv': ('four_variable', 'FourVariable', True, 0.1, 1.5, 1.0),
+    'ev': ('eight_variable', 'EightVariable', True, 0.1, 0.809, 10.0),
 }
 
 

@@ -1,6 +1,5 @@
-"""time the libraries generated from the reference's unchanged model files (oracle/_ref/traced/*.so) next to the
-hand-written kernels: python tools/bench_traced.py [size]"""
-import json
+"""time the kernels GENERATED from model files (tests/models/four_variable.py, eight_variable.py: our own
+transcriptions of the two published models) next to the hand-written kernels: python tools/bench_traced.py [size]"""
 import os
 import sys
 
@@ -8,11 +7,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from fib_tf_amd import _lib  # noqa: E402
-from fib_tf_amd.br import BeelerReuter  # noqa: E402
+from traced_cases import make_model  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-TR = os.path.join(ROOT, 'oracle', '_ref', 'traced')
 
 
 def phase(n):
@@ -30,43 +29,29 @@ def rate(st, ticks):
 def init_for(model):
     if model == 'fenton':
         s = np.zeros((4, N, N), np.float32); s[1:3] = 1; s[0][:, 1] = 1
-    elif model == 'br':
+    else:
         s = np.empty((8, N, N), np.float32)
         for i, v in enumerate((-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)):
             s[i] = v
         s[0][:, 1] = 10
-    else:
-        from fib_tf_amd.court import INITIAL
-        s = np.empty((21, N, N), np.float32)
-        for i, (_, v) in enumerate(INITIAL):
-            s[i] = v
-        s[0][:, :25] = 20
     return s
 
 
-for case, model, mid, flags, ticks in (('fenton_d1.5', 'fenton', _lib.FENTON4V, 0, 500),
-                                       ('br_cheby_d0.809', 'br', _lib.BR, _lib.CHEBY, 300),
-                                       ('court_d0.809', 'court', _lib.COURT, _lib.CHRONIC, 500)):
-    so = os.path.join(TR, case + '.so')
-    if not os.path.exists(so):
-        print(case, 'not built')
-        continue
-    meta = json.load(open(os.path.join(TR, case + '.json')))
+for name, model, mid, ticks in (('fv', 'fenton', _lib.FENTON4V, 500), ('ev', 'br', _lib.BR, 300)):
     ph, init = phase(N), init_for(model)
-    for fast in (1, 0):
-        row = []
-        hand = None
-        if model == 'br':                                   # the product path: table-specialised build (fib_tf_amd/br.py)
-            from fib_tf_amd.br import specialised_library
-            hand = specialised_library(BeelerReuter({'height': 8, 'width': 8, 'cheby': True})._table32())
-        for lib, m, fl in ((_lib.load(so), _lib.CUSTOM, 0), (hand, mid, flags)):
-            st = _lib.Stepper(m, N, N, meta['dt'], meta['diff'], flags=fl | (_lib.FAST if fast else 0), library=lib)
-            if model == 'br' and m == mid:
-                st.set_consts(BeelerReuter({'height': 8, 'width': 8}).chebyshev_table())
-            st.set_phase(ph)
-            st.set_state(-1, init)
-            row.append(rate(st, ticks) + (st.launch_plan(),))
-            st.close()
-        (tr, tus, tp), (nr, nus, np_) = row
-        print('%-18s %4d^2 %-5s traced %9.0f Mcs/s (%7.2f us/tick, plan %s)   hand-written %9.0f Mcs/s (%7.2f us/tick, plan %s)   ratio %.2f'
-              % (case, N, 'fast' if fast else 'exact', tr, tus, tp, nr, nus, np_, tr / nr))
+    for fast in (True, False):
+        m = make_model(name, N, N, fast_math=fast)
+        m.phase = ph
+        m.define()
+        m._stepper.set_state(-1, init)
+        tr, tus = rate(m._stepper, ticks)
+        tp = m._stepper.launch_plan()
+        m._stepper.close()
+        st = _lib.Stepper(mid, N, N, m.dt, m.diff, flags=_lib.FAST if fast else 0)
+        st.set_phase(ph)
+        st.set_state(-1, init)
+        nr, nus = rate(st, ticks)
+        np_ = st.launch_plan()
+        st.close()
+        print('%-4s %4d^2 %-5s generated %9.0f Mcs/s (%7.2f us/tick, plan %s)   hand-written %9.0f Mcs/s (%7.2f us/tick, plan %s)   ratio %.2f'
+              % (name, N, 'fast' if fast else 'exact', tr, tus, tp, nr, nus, np_, tr / nr))
