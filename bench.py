@@ -183,6 +183,7 @@ def counters_for(key):
 def roofline_extras(roof, key, us_per_launch):
     """traffic / issue ceiling / cache hit rates of the dominant kernel from the committed counter passes"""
     rec = counters_for(key)
+    roof['counters_key'] = key
     roof['traffic'] = rec.get('hbm_bytes_per_launch_corrected')
     valu, trans = rec.get('SQ_INSTS_VALU'), rec.get('SQ_INSTS_VALU_TRANS_F32')
     if valu is not None:

@@ -100,6 +100,27 @@ static hipError_t launch_strip(hipStream_t st, const LaunchCtx &c)
     return hipGetLastError();
 }
 
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+static hipError_t launch_rows(hipStream_t st, const LaunchCtx &c)
+{
+    Geo g = c.g;
+    g.tiles_x = (g.W + TX - 1) / TX;
+    g.ty_a = (g.r1 > g.r0) ? (g.r1 - g.r0 + TY - 1) / TY : 0;
+    const int tiles_y = g.ty_a + ((g.rb1 > g.rb0) ? (g.rb1 - g.rb0 + TY - 1) / TY : 0);
+    g.ntiles = g.tiles_x * tiles_y;
+    if (g.ntiles <= 0) return hipSuccess;
+    PtrTab<M::NVAR> pt;
+    for (int v = 0; v < M::NVAR; ++v) {
+        pt.in[v] = c.in[v];
+        pt.out[v] = c.out[v];
+    }
+    constexpr int NT = 64 * ((TY + 2 * (K - 1) + R - 1) / R);
+    const int grid = ((g.ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((rows_kernel<M, P, MODE, K, TX, TY, R, PHASE>), dim3(grid), dim3(NT), 0, st, g, pt, c.ph,
+                       *static_cast<const typename M::Consts *>(c.consts), c.sub0);
+    return hipGetLastError();
+}
+
 template <class M, class P, int MODE>
 static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
 {
@@ -137,6 +158,13 @@ struct Variant {
     {MID, MODE, 1, 0, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, false>},      \
     {MID, MODE, 1, 1, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, true>}
 
+// rows kernels (potential in registers, DPP taps) are listed with NT = -(32 + R)
+#define W4(MODEL, MID, MODE, K, TX, TY, R)                                                         \
+    {MID, MODE, 0, 0, K, TX, TY, -(32 + (R)), launch_rows<MODEL, Exact, MODE, K, TX, TY, R, false>},  \
+    {MID, MODE, 0, 1, K, TX, TY, -(32 + (R)), launch_rows<MODEL, Exact, MODE, K, TX, TY, R, true>},   \
+    {MID, MODE, 1, 0, K, TX, TY, -(32 + (R)), launch_rows<MODEL, Fast, MODE, K, TX, TY, R, false>},   \
+    {MID, MODE, 1, 1, K, TX, TY, -(32 + (R)), launch_rows<MODEL, Fast, MODE, K, TX, TY, R, true>}
+
 // The first matching entry with the wanted K is the default; FIBHIP_VARIANT="K,TX,TY,NT" overrides
 // (tuning sweeps).  Tile shapes: K=1 tiles are wide (coalesced 256-B rows); K>1 tiles are square-ish
 // to keep the redundant rim small.
@@ -157,6 +185,14 @@ static const Variant g_variants[] = {
 #ifndef FIB_CUSTOM_ONLY
 #ifndef FIB_ONLY_BR
     // ---- Fenton 4v ----
+    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 2),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
@@ -533,6 +569,12 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     const double dt = desc->dt, diff = desc->diff;
     h->kf.dt = (float)dt;
     h->kf.ddt = (float)(diff * dt);
+    h->kf.cvp = (float)(1.0 - dt / 3.33);          // tau_vp, tau_vn, tau_wp, tau_wn (fenton.py:60-63)
+    h->kf.cvn = (float)(1.0 - dt / 19.2);
+    h->kf.dvn = (float)(dt / 19.2);
+    h->kf.cwp = (float)(1.0 - dt / 160.0);
+    h->kf.cwn = (float)(1.0 - dt / 75.0);
+    h->kf.dwn = (float)(dt / 75.0);
     h->kb.dt = (float)dt;
     h->kb.ddt = (float)(diff * dt);
     h->kb.mdt = (float)(-dt);

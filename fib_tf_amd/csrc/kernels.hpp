@@ -105,6 +105,30 @@ static FIB_DEV float phase_term(float N, float S, float Wv, float E, float dpy, 
     return Exact::divc((S - N) * dpy + (E - Wv) * dpx, q4, r4);
 }
 
+// The Laplacian of the FUSED kernels under the two arithmetic policies.  Exact: the reference's operations, one
+// rounding each (stencil9 / phase_term).  Fast: the same association order with the two scalings (0.5*, -6*) and the
+// phase quotient contracted into FMAs — 13 instructions instead of 19; every fused kernel uses these two functions, so
+// fusion depth and tile shape still never change a bit of the result within a policy.  (The stand-alone array ops
+// IonicModel.laplace / phase_field keep the exact form under both policies.)
+template <class P>
+static FIB_DEV float lap9(float N, float S, float Wv, float E, float NW, float SW, float NE, float SE, float C)
+{
+    if constexpr (std::is_same<P, Fast>::value) {
+        const float l1 = ((N + S) + Wv) + E, d = ((NW + SW) + NE) + SE;
+        return __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
+    } else {
+        return stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
+    }
+}
+template <class P>
+static FIB_DEV float add_phase(float lap, float N, float S, float Wv, float E, float dpy, float dpx, float q4, float r4)
+{
+    if constexpr (std::is_same<P, Fast>::value)
+        return __builtin_fmaf(__builtin_fmaf(E - Wv, dpx, (S - N) * dpy), r4, lap);
+    else
+        return lap + phase_term<P>(N, S, Wv, E, dpy, dpx, q4, r4);
+}
+
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous run of tiles so
 // that the halos neighbouring tiles share are served by the same L2.  Speed only, never correctness.
 static FIB_DEV int xcd_tile(int b, int ntiles)
@@ -242,12 +266,17 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 const float N = A[i - LP], S = A[i + LP], Wv = A[i - 1], E = A[i + 1];
                 const float NW = A[i - LP - 1], SW = A[i + LP - 1], NE = A[i - LP + 1], SE = A[i + LP + 1];
                 const float C = A[i];
-                float l = ZP ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C) : stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
-                if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + phase_term, IEEE division
+                float l = ZP ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C) : lap9<P>(N, S, Wv, E, NW, SW, NE, SE, C);
+                if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + add_phase (IEEE division = Exact::divc)
                     const float dy = lphi[i + LP] - lphi[i - LP], dx = lphi[i + 1] - lphi[i - 1];
-                    l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);
+                    if constexpr (std::is_same<P, Fast>::value) {
+                        const float q4 = 4.0f * lphi[i];
+                        l = add_phase<P>(l, N, S, Wv, E, dy, dx, q4, 1.0f / q4);           // r4 exactly as phase_prep_kernel forms it
+                    } else {
+                        l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);
+                    }
                 } else if (PHASE) {
-                    l = l + phase_term<P>(N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);   // ionic.py:58
+                    l = add_phase<P>(l, N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);      // ionic.py:58
                 }
                 M::template step<P, TwoPass<M>::first(MODE)>(s[j], C, l, kk, sub0 + st);
             }
@@ -366,35 +395,39 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     const int x0 = bx * TX;
     const int cx0 = x0 - (K - 1), cy0 = y0 - (K - 1);
     const int gx = cx0 - 1 + lane;                                  // this lane's global column
-    const int xx = clampi(gx, 1, g.W - 2);
+    const int c0 = wave * R;                                        // first box row of this wave's strip
 
-    // ---- potential tile through the boundary clamp: one coalesced row per wave-iteration.  All
-    // global loads of the prologue (tile rows here, per-cell state below) are issued before the first
-    // LDS write waits on any of them: one memory latency instead of one per row.
+    // ---- the three tap columns of this lane, through the boundary clamp ------------------------------------
+    // enforce_boundary + REFLECT: a tap at column c reads the raw potential of column clamp(c, 1, W-2).  The clamp
+    // is a property of the LANE, so it lives in the tap ADDRESSES (computed once here) and the tile only ever holds
+    // raw values at their own positions: border and ghost columns need no copies after a sub-step, and a tile at
+    // the left or right edge of the domain costs what an interior tile costs.
+    const int bW = clampi(gx - 1, 1, g.W - 2), bC = clampi(gx, 1, g.W - 2), bE = clampi(gx + 1, 1, g.W - 2);
+    const int jW = clampi(bW - (cx0 - 1), 0, 63), jC = clampi(bC - (cx0 - 1), 0, 63), jE = clampi(bE - (cx0 - 1), 0, 63);
+    auto brow = [&](int grow) {                                     // global row -> local row through the boundary clamp
+        return clampi(clampi(grow, 1, g.Hg - 2) - g.row_off, 0, g.H - 1);
+    };
+
+    // ---- prologue: all global loads are issued before anything waits; the first sub-step's 3 x (R+2) window comes
+    // straight from global memory (no tile fill, no barrier before the step loop)
     const float *vin = pt.in[0];
-    constexpr int NF = (LQ + NW - 1) / NW;
-    float fv[NF];
+    float win[R + 2][3];
 #pragma unroll
-    for (int q = 0; q < NF; ++q) {
-        const int row = min(wave + q * NW, LQ - 1);
-        int yy = clampi(cy0 - 1 + row + g.row_off, 1, g.Hg - 2) - g.row_off;
-        yy = clampi(yy, 0, g.H - 1);
-        fv[q] = vin[(size_t)yy * g.pitch + xx];
+    for (int q = 0; q < R + 2; ++q) {
+        const float *row = vin + (size_t)brow(cy0 + c0 - 1 + q + g.row_off) * g.pitch;
+        win[q][0] = row[bW];
+        win[q][1] = row[bC];
+        win[q][2] = row[bE];
     }
-
-    // ---- per-cell registers ---------------------------------------------------------------------
-    const int la = min(max(lane, 1), 62);                           // keeps every tap of an idle lane in bounds
     const bool lane_in = lane >= 1 && lane <= CX && gx >= 0 && gx < g.W;
     const bool col_border = gx == 0 || gx == g.W - 1;
-    const bool left = gx == 1, right = gx == g.W - 2;               // refresh col 0 / W-1 (+ ghost)
-    const bool left2 = left && lane >= 2, right2 = right && lane <= 61;
-    const bool edge_tile_h = (cx0 <= 1) || (cx0 + CX >= g.W - 1);   // block-uniform
     const bool store_col = lane_in && gx >= x0 && gx < x0 + TX;
+    const bool wr = lane_in && !col_border;                         // this lane's cells are somebody's taps
     float s[R][NV], pdy[R], pdx[R], pq4[R], pr4[R];
     int off[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int gy = cy0 + wave * R + r;
+        const int gy = cy0 + c0 + r;
         const int oy = clampi(gy, 0, g.H - 1), ox = clampi(gx, 0, g.W - 1);
         off[r] = oy * g.pitch + ox;
 #pragma unroll
@@ -410,28 +443,18 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
     // the box reaches the domain edge on that side (no staleness enters through a real boundary)
     const bool top_open = cy0 + g.row_off > 0, bot_open = cy0 + CY + g.row_off < g.Hg;
-#pragma unroll
-    for (int q = 0; q < NF; ++q) {
-        const int row = wave + q * NW;
-        if (row < LQ) {
-            lds[0][row * LP + lane] = fv[q];
-            lds[1][row * LP + lane] = fv[q];
-        }
-    }
+    const int aW = c0 * LP + jW, aC = c0 * LP + jC, aE = c0 * LP + jE;   // window addresses of this strip
     FIB_STAMP(1);
     // all prologue loads are consumed by the first sub-step anyway: drain them once here, so that the
     // compiler does not carry per-use `s_waitcnt vmcnt(n)` into every iteration of the step loop
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0) only
-    __syncthreads();
     FIB_STAMP(2);
 
 #pragma unroll 1
     for (int st = 0; st < K; ++st) {
-        const float *A = lds[st & 1];
         float *B = lds[(st & 1) ^ 1];
         const int need0 = top_open ? st : 0, need1 = bot_open ? CY - st : CY;
         // rows [ra, rb) of this wave's strip are live at this sub-step (wave-uniform)
-        const int c0 = wave * R;
         int ra = max(0, need0 - c0), rb = min(R, need1 - c0);
         ra = max(ra, -(cy0 + c0 + g.row_off));                      // global row >= 0
         rb = min(rb, min(g.Hg - g.row_off, g.H) - (cy0 + c0));      // global row < Hg, local row < H
@@ -439,22 +462,14 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
         if (ra == 0 && rb == R) {
             // ---- whole strip live: one straight-line block.  The R cells of a lane are independent,
             // so the scheduler can interleave their dependency chains; the 3 x (R+2) window is read once.
-            float win[R + 2][3];
-#pragma unroll
-            for (int q = 0; q < R + 2; ++q) {
-                const int i = (c0 + q) * LP + la;
-                win[q][0] = A[i - 1];
-                win[q][1] = A[i];
-                win[q][2] = A[i + 1];
-            }
             float lp[R], cc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float l = stencil9(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
-                                   win[r][2], win[r + 2][2], win[r + 1][1]);
+                float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
+                                  win[r][2], win[r + 2][2], win[r + 1][1]);
                 if (PHASE)
-                    l = l + phase_term<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r], pq4[r],
-                                          pr4[r]);
+                    l = add_phase<P>(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r], pq4[r],
+                                     pr4[r]);
                 lp[r] = l;
                 cc[r] = win[r + 1][1];
             }
@@ -468,52 +483,49 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (r >= ra && r < rb) {                            // scalar branch
-                    const int i = (c0 + r + 1) * LP + la;
-                    const float NW_ = A[i - LP - 1], N = A[i - LP], NE = A[i - LP + 1];
-                    const float Wv = A[i - 1], C = A[i], E = A[i + 1];
-                    const float SW = A[i + LP - 1], S = A[i + LP], SE = A[i + LP + 1];
-                    float l = stencil9(N, S, Wv, E, NW_, SW, NE, SE, C);
-                    if (PHASE) l = l + phase_term<P>(N, S, Wv, E, pdy[r], pdx[r], pq4[r], pr4[r]);
-                    M::template step<P, MODE>(s[r], C, l, kk, sub0 + st);
+                    float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
+                                      win[r][2], win[r + 2][2], win[r + 1][1]);
+                    if (PHASE)
+                        l = add_phase<P>(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r],
+                                         pq4[r], pr4[r]);
+                    M::template step<P, MODE>(s[r], win[r + 1][1], l, kk, sub0 + st);
                 }
             }
         }
-        // ---- publish the new potential for the next sub-step --------------------------------------
+        // ---- publish the new potential, then fetch the next sub-step's window ---------------------------
         if (st + 1 < K) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int cyy = c0 + r;
                 const int gyg = cy0 + cyy + g.row_off;
                 if (r >= ra && r < rb && gyg != 0 && gyg != g.Hg - 1) {     // wave-uniform
-                    const int i = (cyy + 1) * LP + la;
+                    const int i = (cyy + 1) * LP + lane;
                     const float u = s[r][0];
-                    const bool w = lane_in && !col_border;
-                    // own row, plus the border/ghost copies above/below (enforce_boundary + REFLECT);
-                    // the column copies ride along, which also covers the four domain corners
-                    auto put = [&](int o) {
-                        if (w) B[o] = u;
-                        if (edge_tile_h) {
-                            if (w && left) B[o - 1] = u;
-                            if (w && left2) B[o - 2] = u;
-                            if (w && right) B[o + 1] = u;
-                            if (w && right2) B[o + 2] = u;
-                        }
-                    };
-                    put(i);
+                    // own row, plus the border/ghost rows above/below the domain's row 1 / H-2
+                    // (enforce_boundary + REFLECT); the columns need nothing: their clamp is in the tap addresses
+                    if (wr) B[i] = u;
                     if (gyg == 1) {
-                        put(i - LP);
-                        if (cyy >= 1) put(i - 2 * LP);
+                        if (wr) B[i - LP] = u;
+                        if (cyy >= 1 && wr) B[i - 2 * LP] = u;
                     }
                     if (gyg == g.Hg - 2) {
-                        put(i + LP);
-                        if (cyy + 1 < LQ - 2) put(i + 2 * LP);
+                        if (wr) B[i + LP] = u;
+                        if (cyy + 1 < LQ - 2 && wr) B[i + 2 * LP] = u;
                     }
                 }
             }
-        }
-#if !(defined(FIB_STAMPS) && defined(FIB_DIAG_NO_BARRIER))
-        if (st + 1 < K) __syncthreads();
+#ifndef FIB_DIAG_NO_BARRIER                 // (diagnostic builds of tools/ubench/diag_strip.hip only)
+            __syncthreads();
 #endif
+#ifndef FIB_DIAG_NO_RELOAD
+#pragma unroll
+            for (int q = 0; q < R + 2; ++q) {
+                win[q][0] = B[aW + q * LP];
+                win[q][1] = B[aC + q * LP];
+                win[q][2] = B[aE + q * LP];
+            }
+#endif
+        }
         FIB_STAMP(3 + st);
     }
 
@@ -528,6 +540,233 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
         }
     }
     FIB_STAMP(14);
+}
+
+// ---- wavefront-level neighbour access (gfx9 DPP wavefront shifts) -----------------------------------
+// lane i reads the value lane i-1 / i+1 holds: the W / E taps of a row whose columns are the lanes of a
+// wave.  The compiler folds the move into the consuming v_add/v_sub (`v_add_f32_dpp ... wave_shr:1`), so a
+// horizontal tap costs no instruction of its own and no LDS access.  Lane 0 / lane 63 receive 0: they are
+// the ring columns of the compute box, whose results are never used.
+static FIB_DEV float lane_west(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+static FIB_DEV float lane_east(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+static FIB_DEV float lane_get(float v, int lane)     // lane: wave-uniform
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// 9-point Laplacian (+ phase term) of the cell whose row neighbours N, S and own value C sit in THIS lane's
+// registers and whose column neighbours sit in the adjacent lanes.  Same operations in the same order as
+// stencil9 / phase_term: NW + SW is the neighbouring lane's own N + S (the same float32 addition of the same
+// two numbers), so `lane_west(N + S)` is bit-identical to forming it here.
+template <class P, bool PHASE>
+static FIB_DEV float stencil9_lanes(float N, float S, float C, float dpy, float dpx, float q4, float r4)
+{
+    const float ns = N + S;
+    const float Wv = lane_west(C), E = lane_east(C);
+    const float l1 = (ns + Wv) + E, d = (lane_west(ns) + lane_east(N)) + lane_east(S);
+    float r;
+    if constexpr (std::is_same<P, Fast>::value)
+        r = __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
+    else
+        r = (l1 + 0.5f * d) - 6.0f * C;
+    if (PHASE) r = add_phase<P>(r, N, S, Wv, E, dpy, dpx, q4, r4);
+    return r;
+}
+
+// rows_kernel<M,P,MODE,K,TX,TY,R,PHASE> — temporal blocking with the potential in REGISTERS.
+//   Work layout as strip_kernel (lane = column of a 64-wide box, wave = R consecutive rows, K sub-steps per
+//   launch on a box that shrinks by one ring per sub-step), but the potential never lives in an LDS tile:
+//     * a lane keeps the R values of its column strip in registers; the N/S taps of the strip's inner rows are
+//       those registers, the W/E/diagonal taps are DPP wavefront shifts of them (lane_west / lane_east);
+//     * only the strip's first and last row travel between waves: 2 ds_write + 2 ds_read per wave and sub-step
+//       (strip_kernel: 3(R+2) reads + R writes) through a double-buffered [wave][top|bottom][lane] exchange
+//       array, one s_barrier per sub-step;
+//     * sub-step 0 takes its halo rows straight from global memory: no LDS fill, no barrier in the prologue.
+//   Boundary rule (enforce_boundary + REFLECT): a tap at (r, c) reads the raw potential at
+//   (clamp(r,1,H-2), clamp(c,1,W-2)).  Each lane therefore carries, next to the raw value of its cell (Fenton's
+//   reaction reads it on border cells), the ENFORCED value `e` its neighbours see; after a sub-step border and
+//   ghost rows/columns take the new value of the adjacent interior row/column — register copies inside a wave
+//   (readlane across columns), the exchanged edge row between waves.  Only tiles that touch the domain edge
+//   run that code (block-uniform branch; EDGE = false compiles it away).
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE, bool EDGE>
+static FIB_DEV void rows_body(const Geo &g, const PtrTab<M::NVAR> &pt, const PhaseTab &ph, const typename M::Consts &k, int sub0,
+                              int tile, float (*ex)[64])
+{
+    constexpr int NV = M::NVAR;
+    constexpr int CX = TX + 2 * (K - 1), CY = TY + 2 * (K - 1);
+    constexpr int NW = (CY + R - 1) / R;
+    constexpr unsigned WMASK = M::mask(MODE);
+    auto &&kk = M::pinned(k);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
+    int y0, rend;
+    tile_rows(g, by, TY, y0, rend);
+    const int x0 = bx * TX;
+    const int cx0 = x0 - (K - 1), cy0 = y0 - (K - 1);
+    const int gx = cx0 - 1 + lane;                                  // this lane's global column
+    const int c0 = wave * R;                                        // first box row of this wave
+    const int g0 = cy0 + c0 + g.row_off, glast = g0 + R - 1;        // global rows of the strip's first / last row
+    const bool lane_in = lane >= 1 && lane <= CX && gx >= 0 && gx < g.W;
+    const bool store_col = lane_in && gx >= x0 && gx < x0 + TX;
+    const int ox = clampi(gx, 0, g.W - 1);
+    const int bxx = clampi(gx, 1, g.W - 2);                         // column through the boundary clamp
+    FIB_STAMP(0);
+
+    // ---- prologue: every global load is issued before anything waits -------------------------------------
+    float s[R][NV], e[R], pdy[R], pdx[R], pq4[R], pr4[R];
+    int off[R];
+    auto brow = [&](int grow) {                                     // global row -> local row through the boundary clamp
+        return clampi(clampi(grow, 1, g.Hg - 2) - g.row_off, 0, g.H - 1);
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = cy0 + c0 + r;
+        const int oy = clampi(gy, 0, g.H - 1);
+        off[r] = oy * g.pitch + ox;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
+        if (EDGE) e[r] = pt.in[0][(size_t)brow(g0 + r) * g.pitch + bxx];
+        if (PHASE) {
+            const int op = oy * g.W + ox;                           // the phase arrays are always planar
+            pdy[r] = ph.dpy[op];
+            pdx[r] = ph.dpx[op];
+            pq4[r] = ph.q4[op];
+            pr4[r] = ph.r4[op];
+        }
+    }
+    float eN = pt.in[0][(size_t)brow(g0 - 1) * g.pitch + bxx];      // the rows above / below the strip
+    float eS = pt.in[0][(size_t)brow(glast + 1) * g.pitch + bxx];
+    if (!EDGE) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) e[r] = s[r][0];
+    }
+    const bool top_open = cy0 + g.row_off > 0, bot_open = cy0 + CY + g.row_off < g.Hg;
+    // lanes that hold column 1 / W-2 (sources of the border and ghost columns), block-uniform
+    const int l_c1 = clampi(2 - cx0, 0, 63), l_cw = clampi(g.W - 1 - cx0, 0, 63);
+    const bool edge_h = (cx0 <= 1) || (cx0 + CX >= g.W - 1);
+    const bool west_copy = gx <= 0, east_copy = gx >= g.W - 1;
+    FIB_STAMP(1);
+#ifdef FIB_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // diagnostic build: the load latency gets its own stamp
+#endif
+    FIB_STAMP(2);
+
+#pragma unroll 1
+    for (int st = 0; st < K; ++st) {
+        const int need0 = top_open ? st : 0, need1 = bot_open ? CY - st : CY;
+        int ra = max(0, need0 - c0), rb = min(R, need1 - c0);       // live rows of this strip (wave-uniform)
+        ra = max(ra, -(cy0 + c0 + g.row_off));                      // global row >= 0
+        rb = min(rb, min(g.Hg - g.row_off, g.H) - (cy0 + c0));      // global row < Hg, local row < H
+        ra = max(ra, -(cy0 + c0));                                  // local row >= 0
+        if (ra == 0 && rb == R) {
+            float lp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pdy[r], pdx[r],
+                                                 pq4[r], pr4[r]);
+            if constexpr (M::HAS_VEC) {
+                M::template stepN<P, MODE, R>(s, e, lp, kk, sub0 + st);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) M::template step<P, MODE>(s[r], e[r], lp[r], kk, sub0 + st);
+            }
+        } else if (ra < rb) {
+            // (all lanes stay active: the DPP taps of a live row need every lane's registers)
+            float lp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pdy[r], pdx[r],
+                                                 pq4[r], pr4[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r >= ra && r < rb) M::template step<P, MODE>(s[r], e[r], lp[r], kk, sub0 + st);   // scalar branch
+        }
+        if (st + 1 < K) {
+            // ---- the enforced values the next sub-step's taps read --------------------------------------
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!EDGE || (r >= ra && r < rb)) e[r] = s[r][0];
+            if (EDGE) {
+                if (edge_h) {                                       // border + ghost columns <- column 1 / W-2
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float a = lane_get(e[r], l_c1), b = lane_get(e[r], l_cw);
+                        e[r] = west_copy ? a : (east_copy ? b : e[r]);
+                    }
+                }
+                // border + ghost rows whose source row lives in this strip
+#pragma unroll
+                for (int r = R - 2; r >= 0; --r)
+                    if (g0 + r == 0 || g0 + r == -1) e[r] = e[r + 1];
+#pragma unroll
+                for (int r = 1; r < R; ++r)
+                    if (g0 + r == g.Hg - 1 || g0 + r == g.Hg) e[r] = e[r - 1];
+            }
+            // ---- the strip's edge rows, for the waves above and below --------------------------------------
+            float(*slot)[64] = ex + ((st & 1) * NW) * 2;
+            slot[wave * 2 + 0][lane] = e[0];
+            slot[wave * 2 + 1][lane] = e[R - 1];
+            __syncthreads();
+            eN = slot[max(wave - 1, 0) * 2 + 1][lane];
+            eS = slot[min(wave + 1, NW - 1) * 2 + 0][lane];
+            if (EDGE) {
+                if (g0 == 1 || g0 == 0) eN = e[0];                  // the row above is border row 0 / ghost row -1
+                if (glast == g.Hg - 2 || glast == g.Hg - 1) eS = e[R - 1];
+                if (glast == 0) {                                   // my last row is border row 0: row 1 is the next strip's
+                    e[R - 1] = eS;
+                    if (R >= 2) e[R - 2] = eS;
+                }
+                if (g0 == g.Hg - 1) {
+                    e[0] = eN;
+                    if (R >= 2) e[1] = eN;
+                }
+            }
+        }
+        FIB_STAMP(3 + st);
+    }
+
+    // ---- write back -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = cy0 + c0 + r;
+        if (store_col && gy >= y0 && gy < min(y0 + TY, rend) && gy < g.H) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if ((WMASK >> v) & 1u) pt.out[v][off[r]] = s[r][v];
+        }
+    }
+    FIB_STAMP(14);
+}
+
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+__global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
+rows_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0)
+{
+    constexpr int CX = TX + 2 * (K - 1), CY = TY + 2 * (K - 1);
+    static_assert(CX <= 62 && K > 1 && R >= 2, "rows_kernel: compute box must fit 62 lanes, strips of at least 2 rows");
+    constexpr int NW = (CY + R - 1) / R;
+    static_assert(NW <= 16, "rows_kernel: a workgroup has at most 16 waves");
+    __shared__ float ex[2 * NW * 2][64];                            // [parity][wave][top|bottom][lane]
+
+    const int tile = xcd_tile(blockIdx.x, g.ntiles);
+    if (tile >= g.ntiles) return;
+    const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
+    int y0, rend;
+    tile_rows(g, by, TY, y0, rend);
+    const int cx0 = bx * TX - (K - 1), cy0 = y0 - (K - 1) + g.row_off;
+    // does the compute box (with its ring) reach the domain's border rows / columns?  block-uniform
+    const bool edge = cx0 <= 1 || cx0 + CX >= g.W - 1 || cy0 <= 1 || cy0 + NW * R >= g.Hg - 1;
+    if (edge)
+        rows_body<M, P, MODE, K, TX, TY, R, PHASE, true>(g, pt, ph, k, sub0, tile, ex);
+    else
+        rows_body<M, P, MODE, K, TX, TY, R, PHASE, false>(g, pt, ph, k, sub0, tile, ex);
 }
 
 // Pointwise re-evaluation without the stencil: Courtemanche's 'slow' op (court.py:103,615-617).

@@ -19,6 +19,7 @@
 // The formulas follow fenton.py:46-108, br.py:125-332 and court.py:124-429 (cited per block).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace fib {
 
@@ -169,6 +170,18 @@ struct Fast {
         const T e = vmap(t, [](float x) { return __builtin_amdgcn_exp2f(x); });
         return vmap(e + 1.0f, [](float x) { return __builtin_amdgcn_rcpf(x); });
     }
+    // q = 1/(2^x + 1) for an exponent already scaled to base 2 (the caller folds 2*log2(e) and any affine map of its
+    // argument into ONE multiply-add)
+    template <class T>
+    static FIB_DEV T sigm_q2(const T &x)
+    {
+#ifdef FIB_DIAG_NOTRANS                     // (diagnostic builds only: what do the transcendental instructions cost?)
+        return x * 0.001f + 0.5f;
+#else
+        const T e = vmap(x, [](float y) { return __builtin_amdgcn_exp2f(y); });
+        return vmap(e + 1.0f, [](float y) { return __builtin_amdgcn_rcpf(y); });
+#endif
+    }
     template <class T>
     static FIB_DEV T one_plus_tanh(const T &a) { return vfma(sigm_q(a), -2.0f, 2.0f); }
     template <class T>
@@ -249,45 +262,74 @@ struct Fenton {
     struct Consts {
         float dt;      // float(self.dt)
         float ddt;     // float(self.diff * self.dt)   (product formed in double, fenton.py:103)
+        // Fast policy only: the explicit-Euler updates of the two gates with dt folded in on the host (double, rounded
+        // once):  V1 = V*(1 - dt/tau_vp) | V*(1 - dt/tau_vn) + dt/tau_vn,  likewise W (fenton.py:87-88,105-106)
+        float cvp, cvn, dvn, cwp, cwn, dwn;
     };
     static constexpr unsigned mask(int) { return 0xFu; }
 
     template <class P, int MODE>
     static FIB_DEV void step(float (&s)[NVAR], float U0, float lap, const Consts &k, int)
     {
-        body<P, float>(s, U0, lap, k);
+        float dU;
+        pre<P, float>(s, dU, k);
+        post<P, float>(s, dU, U0, lap, k);
     }
     // the R cells of a lane at once (strip kernel): same arithmetic per cell, operation-major order
     static constexpr bool HAS_VEC = true;
+    // The update splits into a part that needs neither the Laplacian nor the enforced potential (the whole reaction
+    // term: it reads the raw U, fenton.py:101) and the potential's own line (fenton.py:103).  (Running the first part
+    // while the stencil window's LDS reads are in flight was tried and bought nothing: with four waves per SIMD that
+    // latency is covered already)
     template <class P, int MODE, int R>
-    static FIB_DEV void stepN(float (&s)[R][NVAR], const float (&U0)[R], const float (&lap)[R], const Consts &k, int)
+    static FIB_DEV void stepN_pre(float (&s)[R][NVAR], float (&dU)[R], const Consts &k)
     {
-        vf<R> t[NVAR], u0, l;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int v = 0; v < NVAR; ++v) t[v].v[r] = s[r][v];
-            u0.v[r] = U0[r];
-            l.v[r] = lap[r];
-        }
-        body<P, vf<R>>(t, u0, l, k);
+        vf<R> t[NVAR], d;
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int v = 0; v < NVAR; ++v) s[r][v] = t[v].v[r];
+            for (int v = 0; v < NVAR; ++v) t[v].v[r] = s[r][v];
+        pre<P, vf<R>>(t, d, k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dU[r] = d.v[r];
+#pragma unroll
+            for (int v = 1; v < NVAR; ++v) s[r][v] = t[v].v[r];
+        }
+    }
+    template <class P, int MODE, int R>
+    static FIB_DEV void stepN_post(float (&s)[R][NVAR], const float (&dU)[R], const float (&U0)[R], const float (&lap)[R],
+                                   const Consts &k)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) post<P, float>(s[r], dU[r], U0[r], lap[r], k);
+    }
+    template <class P, int MODE, int R>
+    static FIB_DEV void stepN(float (&s)[R][NVAR], const float (&U0)[R], const float (&lap)[R], const Consts &k, int)
+    {
+        float dU[R];
+        stepN_pre<P, MODE, R>(s, dU, k);
+        stepN_post<P, MODE, R>(s, dU, U0, lap, k);
     }
     // keep the per-step scalars in VGPRs: a VALU op with an SGPR source issues at ~60 % of the rate
     // of an all-VGPR one (tools/ubench/valu2.hip)
     static FIB_DEV Consts pinned(const Consts &k)
     {
         Consts c = k;
-        asm volatile("" : "+v"(c.dt), "+v"(c.ddt));
+        asm volatile("" : "+v"(c.dt), "+v"(c.ddt), "+v"(c.cvp), "+v"(c.cvn), "+v"(c.dvn), "+v"(c.cwp), "+v"(c.cwn), "+v"(c.dwn));
         return c;
     }
+    // everything but the potential: s[1..3] advance, dU_out = the reaction term of the potential
     template <class P, class T>
-    static FIB_DEV void body(T (&s)[NVAR], const T &U0, const T &lap, const Consts &k)
+    static FIB_DEV void pre(T (&s)[NVAR], T &dU_out, const Consts &k)
     {
 #include "fenton_step.inc"
+    }
+    // U1 = U0 + dt*dU + (diff*dt)*lap(U0), fenton.py:103 (P::mad: two roundings under Exact, one FMA under Fast)
+    template <class P, class T>
+    static FIB_DEV void post(T (&s)[NVAR], const T &dU, const T &U0, const T &lap, const Consts &k)
+    {
+        s[0] = P::mad(lap, k.ddt, P::mad(dU, k.dt, U0));
     }
 };
 

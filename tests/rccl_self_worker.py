@@ -53,11 +53,15 @@ def main(port, out):
     # id broadcast, communicator — on a one-rank group, where there is nothing to exchange afterwards
     from fib_tf_amd.sharded import ShardedStepper
     os.environ['FIBTF_HALO_SELFTEST'] = '1'
+    default = ShardedStepper(_lib.FENTON4V, 64, 48, 0.1, 1.5, flags=_lib.FAST, device=0)
+    default_ok = (not default.rccl_direct) and 'batch_isend_irecv' in default.halo_path     # the default transport
+    default.close()
+    os.environ['FIBTF_HALO'] = 'direct'                    # the library-issued exchange is opt-in
     ss = ShardedStepper(_lib.FENTON4V, 64, 48, 0.1, 1.5, flags=_lib.FAST, device=0)
     ss.set_state(-1, rng.uniform(0, 1, (4, 64, 48)).astype(np.float32))
     ss.step(3)
     full = ss.get_state(-1)
-    setup_ok = bool(ss.rccl_direct and 'ncclSend' in ss.halo_path and np.isfinite(full).all())
+    setup_ok = bool(default_ok and ss.rccl_direct and 'ncclSend' in ss.halo_path and np.isfinite(full).all())
     np.save(out, np.array([ok, slab.is_contiguous(), slab[g:2 * g].is_contiguous(), setup_ok]))
     dist.destroy_process_group()
 

@@ -82,6 +82,7 @@ def test_generated_four_variable_equals_handwritten(gpu_lib, golden, fixture):
         m = make_model('fv', H, W, fast_math=fast, diff=float(f['diff']))
         m.phase = phase
         m.define()
+        m._ensure_compiled()
         assert m.VAR_NAMES == names and m._stepper.launch_plan() == (10, 1)
         m._stepper.set_state(-1, init)
         nat = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, float(f['diff']), flags=_lib.FAST if fast else 0)
@@ -114,6 +115,7 @@ def test_generated_eight_variable_vs_handwritten(gpu_lib, golden):
     m = make_model('ev', H, W, fast_math=False, diff=float(f['diff']))
     m.phase = f['phase']
     m.define()
+    m._ensure_compiled()
     assert m.VAR_NAMES == names and m._stepper.launch_plan() == (5, 1)
     m._stepper.set_state(-1, init)
     nat = _lib.Stepper(_lib.BR, H, W, 0.1, float(f['diff']))

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""condense rocprofv3 csv output (kernel trace + pmc passes) into a short per-kernel summary"""
+"""condense rocprofv3 csv output (kernel trace + pmc passes of tools/prof.sh) into a short per-kernel summary
+(stdout) and a machine-readable record of the dominant kernel (counters.json) that bench.py reads back for
+`roofline.traffic`, `roofline.issue` and `roofline.cache`"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+PASSES = ('pmc_sq', 'pmc_lds', 'pmc_trans', 'pmc_fetch', 'pmc_write', 'pmc_l2', 'pmc_ea', 'pmc_eaw')
 
 
 def short(name):
@@ -33,7 +37,11 @@ for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print('%-112s calls %6d  avg %9.2f us  med %9.2f us  min %8.2f  max %9.2f  %5.1f%%  vgpr/sgpr/lds/grid/wg %s'
           % (n, len(v), sum(v) / len(v) / 1e3, v2[len(v2) // 2] / 1e3, v2[0] / 1e3, v2[-1] / 1e3, 100.0 * sum(v) / tot,
              '/'.join(map(str, meta[n]))))
-for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
+ours = [n for n in dur if 'tick_kernel' in n or 'strip_kernel' in n or 'pointwise' in n]
+dominant = max(ours, key=lambda n: sum(dur[n])) if ours else None
+
+avg = defaultdict(dict)            # kernel -> counter -> per-dispatch average
+for sub in PASSES:
     acc = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(int)
     for f in glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True):
@@ -44,28 +52,31 @@ for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
     if acc:
         print('== %s (per-dispatch averages)' % sub)
     for n, d in acc.items():
-        if 'tick_kernel' not in n and 'pointwise' not in n and 'strip_kernel' not in n:
+        if n not in ours:
             continue
         print('  ' + n)
-        print('     ' + '  '.join('%s=%.4g' % (k, v / cnt[(n, k)]) for k, v in sorted(d.items())))
+        print('     ' + '  '.join('%s=%.6g' % (k, v / cnt[(n, k)]) for k, v in sorted(d.items())))
+        for k, v in d.items():
+            avg[n][k] = v / cnt[(n, k)]
 
-# machine-readable record for bench.py's roofline.traffic (FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
-# FETCH_SIZE under-reports wide coalesced reads by 2x per MI355X_MICROARCH.md "HBM", so both the raw and
-# the corrected figure are kept)
-import json
+# machine-readable record of the dominant kernel.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+# half of a wide coalesced read stream (MI355X_MICROARCH.md "HBM"), so raw and corrected figures are both kept
 rec = {}
-for sub, key in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
-    acc = defaultdict(list)
-    for f in glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == key:
-                acc[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
-    for n, v in acc.items():
-        if 'strip_kernel' in n or 'tick_kernel' in n:
-            rec.setdefault(n, {})[key + '_KiB_per_launch'] = sum(v) / len(v)
-for n, d in rec.items():
-    f, w = d.get('FETCH_SIZE_KiB_per_launch'), d.get('WRITE_SIZE_KiB_per_launch')
+if dominant:
+    d = dict(avg.get(dominant, {}))
+    d['kernel'] = dominant
+    d['us_per_launch_under_trace'] = sum(dur[dominant]) / len(dur[dominant]) / 1e3
+    f, w = d.get('FETCH_SIZE'), d.get('WRITE_SIZE')
     if f is not None and w is not None:
+        d['FETCH_SIZE_KiB_per_launch'], d['WRITE_SIZE_KiB_per_launch'] = f, w
         d['hbm_bytes_per_launch_raw'] = (f + w) * 1024
         d['hbm_bytes_per_launch_corrected'] = (2 * f + w) * 1024
-json.dump(rec, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+    key = None
+    try:
+        line = [l for l in open(os.path.join(out, 'bench_trace.json')) if l.startswith('{')][-1]
+        key = json.loads(line)['roofline'].get('counters_key')
+    except (OSError, IndexError, ValueError, KeyError):
+        pass
+    rec[key or dominant] = d
+json.dump(rec, open(os.path.join(out, 'counters.json'), 'w'), indent=1)
+print('== counters.json key:', list(rec))

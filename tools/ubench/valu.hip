@@ -47,6 +47,22 @@ __global__ void k(float *out, unsigned long long *cyc, float a, float b)
         } else if (MODE == 8) {   // 4 independent chains, 16 instr / iter
 #pragma unroll
             for (int r = 0; r < 4; ++r) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b); }
+        } else if (MODE == 9) {   // 3 chains of DPP adds (wave_shr:1 folded into v_add_f32_dpp), 15 instr / iter
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                x0 = b + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x0), 0x138, 0xF, 0xF, true));
+                x1 = b + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x1), 0x130, 0xF, 0xF, true));
+                x2 = b + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x2), 0x138, 0xF, 0xF, true));
+            }
+        } else if (MODE == 10) {  // 3 chains, one v_exp_f32 + one v_rcp_f32 per 15 instr (the Fenton mix: 4 of 63)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); }
+            x0 = __builtin_amdgcn_exp2f(x0); x1 = __builtin_amdgcn_rcpf(x1); x2 = __builtin_fmaf(x2, a, b);
+        } else if (MODE == 11) {  // 3 chains, fmed3 clamp + mul + add mix, literal constants: 15 instr / iter
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                x0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(x0, 134217728.0f, 0.5f), 0.0f, 1.0f); x1 = x1 * 0.123f; x2 = x2 + 0.77f;
+            }
         } else if (MODE == 5) {   // cndmask / compare mix: 16 instr / iter
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -83,8 +99,8 @@ void run(const char *name, int instr_per_iter)
         double avg = 0; for (auto c : h) avg += c; avg /= nb;
         // s_memtime ticks at 100 MHz? report both: ticks and wall-derived
         const double instr_per_simd = (double)N_ITER * instr_per_iter * wps;
-        printf("%-28s waves/SIMD %d: kernel %.1f us, memtime ticks/wave %.0f, instr/SIMD %.0f -> %.2f ns per wave-instr per SIMD (= %.2f cyc @2.4GHz)\n",
-               name, wps, ms * 1e3, avg, instr_per_simd, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+        printf("%-28s waves/SIMD %d: kernel %.1f us, memtime ticks/wave %.0f, instr/SIMD %.0f -> %.2f ns per wave-instr per SIMD (= %.2f cyc @2.4GHz); by s_memtime: %.2f cyc per wave-instr per SIMD\n",
+               name, wps, ms * 1e3, avg, instr_per_simd, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4, avg / instr_per_simd);
     }
 }
 
@@ -99,5 +115,8 @@ int main()
     run<6>("fma x2 chains", 16);
     run<7>("fma x3 chains", 15);
     run<8>("fma x4 chains", 16);
+    run<9>("add_dpp wave_shr x3 chains", 15);
+    run<10>("fma x3 + exp + rcp per 15", 15);
+    run<11>("fmed3(fma)+mul+add x3", 20);
     return 0;
 }
