@@ -185,26 +185,26 @@ static const Variant g_variants[] = {
 #ifndef FIB_CUSTOM_ONLY
 #ifndef FIB_ONLY_BR
     // ---- Fenton 4v ----
-    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 2),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
-    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
+    // K = 10 (the whole tick in one launch) and K = 5 strips of growing tile height: build_plan picks the shape
+    // that gives every CU at most one tile (or the fewest rounds) for the grid at hand
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 4),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 5),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 6),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 36, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 40, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 44, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 27, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 32, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 40, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 44, 4),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 56, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 2, 60, 18, 4),
+    // the same blocking with the potential in registers and DPP taps (rows_kernel): selectable, not a default
+    W4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
+    W4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 512),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 1024),
     V4(Fenton, FIBHIP_FENTON4V, 0, 10, 32, 32, 256),
@@ -295,6 +295,7 @@ struct fibhip_ctx {
     int own0, own1;         // owned local rows
     bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
     bool pending;           // fibhip_step's last tick has not been launched yet (see lazy_fusable)
+    bool tuned;             // the plan has been checked against the other tile shapes on this very geometry (autotune)
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
                             // cpos = ticks done since the last exchange
@@ -372,6 +373,7 @@ static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /
 static int build_plan(fibhip_ctx *h)
 {
     h->plan.clear();
+    h->tuned = false;
     int prefK = 0, want[3], nwant = 0;
     if (const char *e = getenv("FIBHIP_VARIANT")) {
         int k = 0;
@@ -636,6 +638,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->pending = false;
     h->fused_fn = nullptr;
     h->comm = nullptr;
+    h->tuned = false;
     return build_plan(h);
 }
 
@@ -868,10 +871,87 @@ static int check_ready(fibhip_ctx *h)
     return 0;
 }
 
+// Plan selection by measurement.  The K-fused Fenton kernel exists in a family of tile shapes (K = 10 or 5, tile
+// heights 21..56): which one is fastest depends on how the grid's tiles land on the 256 CUs — a launch costs about the
+// same whether a CU gets one tile or none, and nearly twice as much with two — so fixed size thresholds leave cliffs
+// (576^2: 26.7 us per tick with the 512^2 choice, 18.9 with a taller tile).  The first tick of a handle therefore
+// times every candidate ONCE on the handle's own geometry (its real launch: same buffers, same rows; a candidate
+// writes what the real launch overwrites) and keeps the fastest.  All candidates are bit-identical in their results
+// (tests/test_gpu_parity.py::test_fenton_fusion_depths_bit_identical), so the choice changes speed only — ranks of
+// a sharded grid may choose differently.  FIBHIP_AUTOTUNE=0, FIBHIP_VARIANT or FIBHIP_K switch it off.
+static int autotune(fibhip_ctx *h)
+{
+    h->tuned = true;
+    if (h->d.model != FIBHIP_FENTON4V || (h->d.flags & FIBHIP_ZEROPAD)) return 0;
+    if (getenv("FIBHIP_VARIANT") || getenv("FIBHIP_K")) return 0;
+    if (const char *e = getenv("FIBHIP_AUTOTUNE"))
+        if (atoi(e) == 0) return 0;
+    const int maxghost = (h->d.ghost_top > 0 || h->d.ghost_bottom > 0)
+                             ? imin(h->d.ghost_top > 0 ? h->d.ghost_top : 1 << 30, h->d.ghost_bottom > 0 ? h->d.ghost_bottom : 1 << 30)
+                             : 1 << 30;
+    const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
+    const std::vector<PlanItem> heuristic = h->plan;
+    // a trial launch must not change the state: only launches that fuse K > 1 sub-steps write every array to the
+    // OTHER slab (one sub-step per launch updates the pointwise arrays in place)
+    for (const PlanItem &it : heuristic)
+        if (it.K < 2) return 0;
+    const long launches0 = h->launches;
+    std::vector<PlanItem> best_plan = heuristic;
+    float best_ms = 1e30f;
+    bool heuristic_timed = false;
+    for (int i = -1; i < g_nvariants; ++i) {
+        std::vector<PlanItem> trial;
+        if (i < 0) {
+            trial = heuristic;                                    // the rule-based plan is a candidate like any other
+        } else {
+            const Variant &v = g_variants[i];
+            if (v.model != FIBHIP_FENTON4V || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
+            if (v.NT >= 0 || v.NT <= -32 || v.K < 2 || h->spt % v.K != 0 || v.K > maxghost) continue;   // strip kernels
+            if (!heuristic.empty() && heuristic[0].fn == v.fn && heuristic_timed) continue;
+            for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX});
+        }
+        if (trial.empty()) continue;
+        h->plan = trial;
+        float ms_tick = 0.f;
+        int sub = 0;
+        bool ok = true;
+        for (size_t l = 0; l < trial.size() && ok; ++l) {          // every launch of the tick, with the rows edges_impl gives it
+            LaunchCtx c;
+            int nxt[FIB_MAXVAR];
+            fill_ptrs(h, c, trial[l].K, h->cur, nxt);             // ALWAYS current slab -> other slab: the state stays put
+            c.sub0 = sub;
+            int r0, r1;
+            rows_of_launch(h, l, r0, r1);
+            float best_l = 1e30f;
+            for (int rep = 0; rep < 4 && ok; ++rep) {             // first repetition = warm-up (code object, caches)
+                HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+                if (launch_range(h, h->s0, trial[l], c, r0, r1)) ok = false;
+                HIPCHK(hipEventRecord(h->ev_t1, h->s0));
+                HIPCHK(hipEventSynchronize(h->ev_t1));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+                if (rep > 0 && ms < best_l) best_l = ms;
+            }
+            ms_tick += best_l;
+            sub += trial[l].K;
+        }
+        if (i < 0) heuristic_timed = true;
+        if (ok && ms_tick < best_ms) {
+            best_ms = ms_tick;
+            best_plan = trial;
+        }
+    }
+    h->plan = best_plan;
+    h->launches = launches0;
+    return 0;
+}
+
 static int edges_impl(fibhip_t h)
 {
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step_edges: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
+    if (!h->tuned)
+        if (int rc = autotune(h)) return rc;
     int cur[FIB_MAXVAR];
     memcpy(cur, h->cur, sizeof cur);
     int sub = 0;
@@ -1459,6 +1539,10 @@ extern "C" int fibhip_halo_due(fibhip_t h)
 extern "C" int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    if (!h->tuned && h->phase_of_tick == 0 && !h->pending && check_ready(h) == 0) {   // report the plan that will run
+        HIPCHK(hipSetDevice(h->d.device));
+        if (int rc = autotune(h)) return rc;
+    }
     if (fused_steps) *fused_steps = h->plan.empty() ? 0 : h->plan[0].K;
     if (launches_per_tick) *launches_per_tick = (int)h->plan.size();
     return 0;

@@ -238,9 +238,9 @@ def run_to(model, ticks, hook=None):
 
 
 # (NT < -32: rows_kernel, potential in registers + DPP taps, with R = -NT - 32 rows per wave)
-FENTON_VARIANTS = ['', '5,54,21,-34', '10,44,25,-35', '10,44,25,-36', '10,44,25,-37', '10,44,28,-35', '5,54,23,-35',
-                   '5,54,22,-36', '5,54,21,-35', '10,44,28,-3', '10,44,25,-4', '10,44,25,-3', '10,44,25,-5', '10,44,25,-6', '10,44,32,-4', '5,54,21,-4',
-                   '5,54,21,-3', '5,54,32,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512',
+FENTON_VARIANTS = ['', '10,44,25,-35', '5,54,21,-35', '10,44,28,-3', '10,44,25,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4',
+                   '10,44,44,-4', '5,54,21,-3', '5,54,23,-3', '5,54,22,-4', '5,54,27,-3', '5,54,32,-4', '5,54,40,-3', '5,54,44,-4',
+                   '5,54,56,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512',
                    '5,32,16,256', '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256']
 
 
@@ -277,9 +277,9 @@ def test_fenton_fusion_depths_bit_identical(gpu_lib, monkeypatch, policy):
     a hole, after 30 sub-steps"""
     from fib_tf_amd.fenton import Fenton4v
     res = {}
-    for variant in ('1,64,4,256', '10,32,32,512', '5,32,32,256', '2,64,16,256', '10,32,32,1024', '10,44,25,-4',
-                    '5,54,21,-34', '10,44,25,-35', '10,44,25,-36', '10,44,25,-37', '10,44,28,-35', '5,54,23,-35',
-                    '5,54,22,-36', '5,54,21,-35', '10,44,25,-3', '10,44,32,-4', '5,54,21,-4', '5,54,32,-4', '2,60,18,-4'):
+    for variant in ('1,64,4,256', '10,32,32,512', '5,32,32,256', '2,64,16,256', '10,32,32,1024', '10,44,25,-35', '5,54,21,-35',
+                    '10,44,25,-3', '10,44,28,-3', '10,44,32,-4', '10,44,44,-4', '5,54,21,-3', '5,54,22,-4', '5,54,27,-3',
+                    '5,54,32,-4', '5,54,40,-3', '5,54,56,-4', '2,60,18,-4'):
         monkeypatch.setenv('FIBHIP_VARIANT', variant)
         m = Fenton4v(cfg(45, 70, 1.1, policy))
         m.add_hole_to_phase_field(30, 20, 7)
@@ -651,7 +651,7 @@ def test_fenton_tiny_and_skinny_grids(gpu_lib, orc, shape, monkeypatch):
     ref = st.copy()
     orc.fenton_run(ref, 0.1, 1.2, phi, 20)
     for variant in ('', '1,64,4,256', '5,32,32,256', '10,32,32,512', '5,54,21,-3', '2,60,18,-4', '10,44,25,-35',
-                    '5,54,21,-34', '5,54,22,-36', '5,54,21,-35'):
+                    '5,54,21,-35', '10,44,25,-3', '10,44,44,-4', '5,54,56,-4'):
         if variant:
             monkeypatch.setenv('FIBHIP_VARIANT', variant)
         else:

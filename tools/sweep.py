@@ -10,9 +10,9 @@ import argparse
 import bench
 
 VARIANTS = {
-    'fenton': ['5,54,21,-34', '10,44,25,-35', '10,44,25,-36', '10,44,25,-37', '10,44,28,-35', '5,54,23,-35', '5,54,22,-36',
-               '5,54,21,-35', '10,44,28,-3', '10,44,25,-4', '10,44,25,-3', '10,44,25,-5', '10,44,25,-6', '10,44,32,-4', '5,54,21,-4', '5,54,22,-4', '5,54,21,-3', '5,54,23,-3',
-               '5,54,32,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512', '5,32,16,256',
+    'fenton': ['10,44,25,-35', '5,54,21,-35', '10,44,25,-3', '10,44,28,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4', '10,44,44,-4',
+               '5,54,21,-3', '5,54,23,-3', '5,54,22,-4', '5,54,27,-3', '5,54,32,-4', '5,54,40,-3', '5,54,44,-4', '5,54,56,-4',
+               '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512', '5,32,16,256',
                '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256'],
     'br': ['2,60,19,-2', '2,60,19,-3', '3,58,19,-2', '5,54,21,-3', '5,54,21,-2', '5,32,32,256', '5,32,32,512', '1,64,16,256', '1,64,4,256'],
     'court': ['1,64,4,256', '1,64,8,256'],
