@@ -223,6 +223,9 @@ static const Variant g_variants[] = {
 #endif
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 24, 2),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 27, 3),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
@@ -234,6 +237,9 @@ static const Variant g_variants[] = {
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
 #endif
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 24, 2),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 27, 3),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
@@ -871,8 +877,9 @@ static int check_ready(fibhip_ctx *h)
     return 0;
 }
 
-// Plan selection by measurement.  The K-fused Fenton kernel exists in a family of tile shapes (K = 10 or 5, tile
-// heights 21..56): which one is fastest depends on how the grid's tiles land on the 256 CUs — a launch costs about the
+// Plan selection by measurement (Fenton 4v and Beeler-Reuter).  The K-fused kernels exist in a family of tile shapes
+// (Fenton: K = 10 or 5, tile heights 21..56; Beeler-Reuter: K = 5, heights 21..40, or one sub-step per launch): which
+// one is fastest depends on how the grid's tiles land on the 256 CUs — a launch costs about the
 // same whether a CU gets one tile or none, and nearly twice as much with two — so fixed size thresholds leave cliffs
 // (576^2: 26.7 us per tick with the 512^2 choice, 18.9 with a taller tile).  The first tick of a handle therefore
 // times every candidate ONCE on the handle's own geometry (its real launch: same buffers, same rows; a candidate
@@ -882,7 +889,7 @@ static int check_ready(fibhip_ctx *h)
 static int autotune(fibhip_ctx *h)
 {
     h->tuned = true;
-    if (h->d.model != FIBHIP_FENTON4V || (h->d.flags & FIBHIP_ZEROPAD)) return 0;
+    if ((h->d.model != FIBHIP_FENTON4V && h->d.model != FIBHIP_BR) || (h->d.flags & FIBHIP_ZEROPAD) || h->spt < 2) return 0;
     if (getenv("FIBHIP_VARIANT") || getenv("FIBHIP_K")) return 0;
     if (const char *e = getenv("FIBHIP_AUTOTUNE"))
         if (atoi(e) == 0) return 0;
@@ -891,10 +898,6 @@ static int autotune(fibhip_ctx *h)
                              : 1 << 30;
     const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
     const std::vector<PlanItem> heuristic = h->plan;
-    // a trial launch must not change the state: only launches that fuse K > 1 sub-steps write every array to the
-    // OTHER slab (one sub-step per launch updates the pointwise arrays in place)
-    for (const PlanItem &it : heuristic)
-        if (it.K < 2) return 0;
     const long launches0 = h->launches;
     std::vector<PlanItem> best_plan = heuristic;
     float best_ms = 1e30f;
@@ -905,35 +908,39 @@ static int autotune(fibhip_ctx *h)
             trial = heuristic;                                    // the rule-based plan is a candidate like any other
         } else {
             const Variant &v = g_variants[i];
-            if (v.model != FIBHIP_FENTON4V || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
-            if (v.NT >= 0 || v.NT <= -32 || v.K < 2 || h->spt % v.K != 0 || v.K > maxghost) continue;   // strip kernels
+            if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
+            // strip kernels of every fusion depth, and the one-sub-step-per-launch tiles
+            const bool strip = v.NT < 0 && v.NT > -32 && v.K >= 2, single = v.NT > 0 && v.K == 1;
+            if (!(strip || single) || h->spt % v.K != 0 || v.K > maxghost) continue;
             if (!heuristic.empty() && heuristic[0].fn == v.fn && heuristic_timed) continue;
             for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX});
         }
         if (trial.empty()) continue;
         h->plan = trial;
-        float ms_tick = 0.f;
-        int sub = 0;
+        // the whole tick back to back between one pair of events (the gaps between its launches are part of its
+        // cost), best of three after a warm-up pass (code objects, caches)
+        float ms_tick = 1e30f;
         bool ok = true;
-        for (size_t l = 0; l < trial.size() && ok; ++l) {          // every launch of the tick, with the rows edges_impl gives it
-            LaunchCtx c;
-            int nxt[FIB_MAXVAR];
-            fill_ptrs(h, c, trial[l].K, h->cur, nxt);             // ALWAYS current slab -> other slab: the state stays put
-            c.sub0 = sub;
-            int r0, r1;
-            rows_of_launch(h, l, r0, r1);
-            float best_l = 1e30f;
-            for (int rep = 0; rep < 4 && ok; ++rep) {             // first repetition = warm-up (code object, caches)
-                HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+        for (int rep = 0; rep < 4 && ok; ++rep) {
+            HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+            int sub = 0;
+            for (size_t l = 0; l < trial.size() && ok; ++l) {      // every launch with the rows edges_impl gives it
+                LaunchCtx c;
+                int nxt[FIB_MAXVAR];
+                fill_ptrs(h, c, trial[l].K, h->cur, nxt);         // ALWAYS current slab -> other slab: the state stays put
+                for (int v = 0; v < h->nvar; ++v)                 // (a K = 1 launch would update the pointwise arrays in place)
+                    c.out[v] = h->slab[h->cur[v] ^ 1] + (size_t)v * h->vstride;
+                c.sub0 = sub;
+                int r0, r1;
+                rows_of_launch(h, l, r0, r1);
                 if (launch_range(h, h->s0, trial[l], c, r0, r1)) ok = false;
-                HIPCHK(hipEventRecord(h->ev_t1, h->s0));
-                HIPCHK(hipEventSynchronize(h->ev_t1));
-                float ms = 0.f;
-                HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
-                if (rep > 0 && ms < best_l) best_l = ms;
+                sub += trial[l].K;
             }
-            ms_tick += best_l;
-            sub += trial[l].K;
+            HIPCHK(hipEventRecord(h->ev_t1, h->s0));
+            HIPCHK(hipEventSynchronize(h->ev_t1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+            if (rep > 0 && ms < ms_tick) ms_tick = ms;
         }
         if (i < 0) heuristic_timed = true;
         if (ok && ms_tick < best_ms) {

@@ -144,7 +144,8 @@ def test_br_specialised_build_is_bit_identical(gpu_lib, policy, skip):
             pass
         res.append(np.stack([m._State[k].eval() for k in m.VAR_NAMES]))
         if spec:
-            assert '_spec' in m._library._name and m._stepper.launch_plan() == (5, 1)
+            fused, launches = m._stepper.launch_plan()        # (chosen by measurement: any split of the 5 sub-steps)
+            assert '_spec' in m._library._name and fused * launches == 5
     assert np.array_equal(res[0], res[1])
 
 
