@@ -334,7 +334,7 @@ def bench_single(args):
     }
     try:                                              # achievable-bandwidth yardstick, measured in this very run
         from fib_tf_amd import _lib
-        out['roofline']['copy_bandwidth_measured'] = round(_lib.copy_bandwidth(1 << 30, 5, m.device), 1)
+        out['roofline']['copy_bandwidth_measured'] = round(_lib.copy_bandwidth(1 << 30, 5, m.device, library=m._library), 1)
     except Exception as e:                            # never lose the result line over the yardstick
         out['roofline']['copy_bandwidth_measured'] = None
         print('copy bandwidth not measured: %s' % e, file=sys.stderr)

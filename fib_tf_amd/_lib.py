@@ -191,10 +191,12 @@ COURT_INTER_KEYS = ('d_infinity', 'tau_d', 'f_infinity', 'tau_f', 'tau_w', 'w_in
                     'f_NaK', 'i_NaCaa', 'i_NaCab', 'i_K1a', 'i_Kra', 'us_infinity', 'tau_us')
 
 
-def copy_bandwidth(nbytes=1 << 30, reps=5, device=0):
-    """GB/s (read + written) of a plain streaming copy on the device: the achievable-HBM yardstick"""
+def copy_bandwidth(nbytes=1 << 30, reps=5, device=0, library=None):
+    """GB/s (read + written) of a plain streaming copy on the device: the achievable-HBM yardstick.
+    `library`: the build of libfibhip the caller is already running kernels from (a specialised or traced build)"""
+    L = library or lib()
     out = C.c_float()
-    check(lib().fibhip_copy_bandwidth(device, nbytes, reps, C.byref(out)))
+    check(L.fibhip_copy_bandwidth(device, nbytes, reps, C.byref(out)), L)
     return out.value
 
 
