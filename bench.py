@@ -205,9 +205,10 @@ def roofline_extras(roof, key, us_per_launch):
         for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_WRREQ_sum', 'TCC_EA0_WRREQ_DRAM_sum'):
             if rec.get(k) is not None:
                 roof['cache'][k] = round(rec[k])
-        rd, rdd = rec.get('TCC_EA0_RDREQ_sum'), rec.get('TCC_EA0_RDREQ_DRAM_sum')
-        if rd and rdd is not None:
-            roof['cache']['infinity_cache_read_hit_rate'] = round(1.0 - rdd / rd, 4)
+        roof['cache']['note'] = ('TCC_HIT/MISS: the XCDs\' L2s.  TCC_EA0_*REQ: 64-B requests leaving the L2s towards the '
+                                 'fabric; on gfx950 the _DRAM variants count the same requests (Infinity-Cache hits are not '
+                                 'told apart, MI355X_MICROARCH.md "HBM"), so no Infinity-Cache hit rate can be derived; the '
+                                 'working set of this launch is far below its 256 MiB')
     if rec:
         roof['counters_source'] = '%s [%s], kernel %s' % (rec.get('source'), key, rec.get('kernel', '?'))
     return roof
@@ -418,7 +419,8 @@ def spawn_ranks(args):
     if rc == 0 and not lines:
         print('bench.py: rank 0 printed no result line', file=sys.stderr)
         rc = 1
-    sys.stdout.write(out)
+    for l in out.splitlines():                        # the result line to stdout, anything else a library printed to stderr
+        (sys.stdout if l.startswith('{') else sys.stderr).write(l + '\n')
     sys.stdout.flush()
     return rc
 

@@ -467,12 +467,13 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0) only
     FIB_STAMP(2);
 
-// two sub-steps per loop body: the loop-carried state then needs no register moves at the back edge (measured:
+    // two sub-steps per loop body: the loop-carried state then needs no register moves at the back edge (measured:
     // -5 % under Exact, -7 % for R = 4 strips, nothing for Fast R = 3; tools/ubench/diag_strip.hip)
 #ifndef FIB_STEP_UNROLL
 #define FIB_STEP_UNROLL 2
 #endif
-#pragma unroll FIB_STEP_UNROLL
+    constexpr int STEP_UNROLL = FIB_STEP_UNROLL;
+#pragma unroll STEP_UNROLL
     for (int st = 0; st < K; ++st) {
         float *B = lds[(st & 1) ^ 1];
         // rows [ra, rb) of this wave's strip are live at this sub-step (wave-uniform): the box loses one ring per
