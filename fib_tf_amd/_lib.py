@@ -15,7 +15,7 @@ SRC = os.path.join(HERE, 'csrc', 'fibhip.hip')
 HDR = os.path.join(ROOT, 'include', 'fibhip.h')
 
 FENTON4V, BR, COURT, COURT_US, CUSTOM = 0, 1, 2, 3, 4
-CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED, ZEROPAD = 1, 2, 4, 8, 16, 32, 64
+CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED, ZEROPAD, HOLD = 1, 2, 4, 8, 16, 32, 64, 128
 
 # -ffp-contract=off: FMAs appear only where the source writes them (policy hook P::mad).
 # -fno-slp-vectorize: SLP packs pairs of f32 ops into v_pk_* instructions, which issue at half rate on

@@ -80,7 +80,8 @@ class BeelerReuter(IonicModel):
             dtype=np.float32)
 
     def _flags(self):
-        return (super()._flags() | (_lib.CHEBY if self.cheby else 0) | (_lib.SKIP if self.skip else 0))
+        return (super()._flags() | (_lib.CHEBY if self.cheby else 0) | (_lib.SKIP if self.skip else 0)
+                | (_lib.HOLD if getattr(self, '_hold', False) else 0))
 
     # ---- definition-time Chebyshev machinery (host, float64) ------------------------------------
     def calc_alpha_beta_np(self):
@@ -153,15 +154,16 @@ class BeelerReuter(IonicModel):
 
     def solve(self, state, n=1):
         """ONE sub-step of (V, C, M, H, J, D, F, XI) host arrays on the GPU (br.py:125-173).
-        n = number of dt the slow gates advance: 1, or 5 (the first sub-step of a skip tick)."""
-        if n not in (1, 5):
-            raise ValueError('solve: n must be 1 or 5 (n=0 only occurs inside a skip tick)')
+        n = number of dt the slow gates advance: 1; 5 (the first sub-step of a skip tick); 0 (its other four
+        sub-steps: xi, j, d, f are carried over unchanged, br.py:98-103)."""
+        if n not in (0, 1, 5):
+            raise ValueError('solve: n must be 0, 1 or 5')
         keep = self.skip
-        self.skip = (n == 5)
+        self.skip, self._hold = (n == 5), (n == 0)
         try:
             st = self._new_stepper(steps_per_tick=1, shard=False)
         finally:
-            self.skip = keep
+            self.skip, self._hold = keep, False
         try:
             st.set_state(-1, np.stack([np.asarray(a, np.float32) for a in state]))
             st.step(1)

@@ -587,7 +587,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->kb.ddt = (float)(diff * dt);
     h->kb.mdt = (float)(-dt);
     h->kb.mdt_skip = (float)(-(dt * 5));
-    h->kb.skip = (desc->flags & FIBHIP_SKIP) ? 1 : 0;
+    h->kb.skip = (desc->flags & FIBHIP_HOLD) ? 2 : ((desc->flags & FIBHIP_SKIP) ? 1 : 0);
     memset(h->kb.cheb, 0, sizeof h->kb.cheb);
     {
         const bool all = (desc->flags & FIBHIP_ALLVARS) != 0 || desc->model == FIBHIP_COURT_US;

@@ -52,6 +52,8 @@ enum fibhip_flags {
                               /* 107-111,127-128) instead of the fast/slow split                           */
     FIBHIP_ZEROPAD = 1u << 6, /* Laplacian of fenton_simple.py / fenton_jit.py: a 3x3 convolution with zero padding        */
                               /* (fenton_simple.py:38-49) instead of IonicModel.laplace; single device only              */
+    FIBHIP_HOLD    = 1u << 7, /* BR: the slow gates xi, j, d, f are not advanced at all: BeelerReuter.solve(state, 0),  */
+                              /* the sub-steps 1..4 of a `skip` tick taken on their own (br.py:98-103,195-205)         */
     FIBHIP_ROW_INTERLEAVED = 1u << 5 /* device slab layout [height][nvar][width] instead of               */
                               /* [nvar][height][width]: the rows a row block exchanges with a neighbour    */
                               /* (all arrays) are then ONE contiguous block.  Host-side get/set_state keep  */

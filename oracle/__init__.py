@@ -71,6 +71,7 @@ def lib():
             fn.argtypes, fn.restype = args, None
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_set_exp_ulps.argtypes = [C.c_int]
         _lib.orc_set_threads(host_cores())
     return _lib
 
@@ -241,6 +242,11 @@ def host_cores():
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+def set_exp_ulps(k):
+    """test knob: every expf result of the oracle moved by k float32 neighbours (0 = plain libm)"""
+    lib().orc_set_exp_ulps(int(k))
 
 
 def num_threads():

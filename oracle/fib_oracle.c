@@ -29,6 +29,21 @@
 
 #define F(x) ((float)(x))
 
+/* Test knob (default 0 = plain libm): every expf result moved by `orc_exp_ulps` float32 neighbours.  It models "any
+ * exp() within that many ulp of libm's" — TensorFlow's Eigen kernels, NumPy's SIMD loops and the GPU's v_exp_f32 all
+ * are such implementations.  The parity tests use it to bound what the reference's own ill-conditioned quotients
+ * (the removable singularities of court.py:303-410) do to the last bit of exp. */
+static int orc_exp_ulps = 0;
+void orc_set_exp_ulps(int k) { orc_exp_ulps = k; }
+static inline float orc_expf(float x)
+{
+    float r = expf(x);
+    for (int k = orc_exp_ulps; k > 0; --k) r = nextafterf(r, INFINITY);
+    for (int k = orc_exp_ulps; k < 0; ++k) r = nextafterf(r, -INFINITY);
+    return r;
+}
+#define expf(x) orc_expf(x)
+
 /* ------------------------------------------------------------------------- */
 /* geometry helpers                                                           */
 /* ------------------------------------------------------------------------- */

@@ -107,7 +107,7 @@ def test_fenton_single_step(gpu_lib, golden, variant, policy):
 
 @pytest.mark.parametrize('policy', POLICIES)
 @pytest.mark.parametrize('cheby', [False, True])
-@pytest.mark.parametrize('n', [1, 5])
+@pytest.mark.parametrize('n', [0, 1, 5])
 def test_br_single_step(gpu_lib, golden, cheby, n, policy):
     from fib_tf_amd.br import BeelerReuter
     f = golden('br_step')
@@ -125,6 +125,8 @@ def test_br_single_step(gpu_lib, golden, cheby, n, policy):
             # reference's, amplified ~1e2 by the sums (the h/j fits are poorly conditioned, br.py:289-301)
             tol = 1e-4
         assert_close(o, want, tol, 'br %s %s n=%d [%s]' % (tag, k, n, policy), scale=scale)
+        if n == 0 and k in ('J', 'D', 'F', 'XI'):      # solve(state, 0) carries the slow gates over: bit for bit
+            assert np.array_equal(o, f[k])
 
 
 @pytest.mark.parametrize('policy', POLICIES)
@@ -204,15 +206,34 @@ def test_court_single_step(gpu_lib, golden, orc, chronic, policy):
         near |= np.abs(V - np.float32(s)) < 0.06
         exact |= V == np.float32(s)
     tag = 'chronic' if chronic else 'acute'
+    # Near a removable singularity the comparison is against the ORACLE'S OWN SENSITIVITY there: the same step
+    # evaluated with exp() moved by -1/0/+1 ulp and every potential by -2 .. +2 float32 neighbours.  What the reference
+    # formula does to one ulp of exp and of its input is the honest error bar of ANY float32 evaluation of it; the
+    # device value must lie inside the envelope of those fifteen answers (and the golden one), widened by three times its own width plus the ordinary
+    # tolerance.  (Width for the 62 near cells of the fixture: median 0 .. 1e-5 of the variable's range, 0.85 for the
+    # one cell a few ulp from V = -14.1, where the reference's own xr rate is noise; the old blanket bound was 0.2.)
+    slab = np.stack([f[k] for k in orc.COURT_VARS])
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_golden import court_envelope_samples
+    samples = court_envelope_samples(orc, slab, f['phase'], chronic)
     scales = {'V': 150.0, '_Na_i_': 3.0, '_K_i_': 15.0, '_Ca_i_': 1e-3, '_Ca_rel_': 1.5, '_Ca_up_': 1.0}
-    for k in m.VAR_NAMES:
+    for i, k in enumerate(m.VAR_NAMES):
+        assert orc.COURT_VARS[i] == k
         want = f['%s_1_%s' % (k, tag)]
         sc = scales.get(k, 1.0)
-        d = np.abs(out[k].astype(np.float64) - want)
+        got = out[k].astype(np.float64)
+        d = np.abs(got - want)
         assert np.isfinite(out[k]).all(), k
         ok = ~near | exact
-        assert d[ok].max() <= (6e-6 if policy == 'exact' else 4e-5) * sc, '%s: %.3e' % (k, d[ok].max())
-        assert d.max() <= 0.2 * sc, '%s near singularity: %.3e' % (k, d.max())
+        tol = (6e-6 if policy == 'exact' else 4e-5) * sc
+        assert d[ok].max() <= tol, '%s: %.3e' % (k, d[ok].max())
+        lo = np.minimum(samples[:, i].min(axis=0), want)
+        hi = np.maximum(samples[:, i].max(axis=0), want)
+        margin = 3.0 * (hi - lo) + tol
+        outside = np.maximum(lo - margin - got, got - hi - margin)
+        assert outside[near].max() <= 0.0, '%s near a singularity: %.3e outside the oracle\'s sensitivity envelope (width %.3e)' % (
+            k, outside[near].max(), (hi - lo)[near].max())
 
 
 def test_court_calc_inter_reference_binary(orc):
