@@ -11,8 +11,8 @@
 // time): that is how Courtemanche's fast / slow assign groups (court.py:94-103) are built.
 //
 // P is the arithmetic policy:
-//   Exact — one float32 rounding per reference op: IEEE division, ocml expf/expm1f/logf/tanhf,
-//           no FMA contraction (the translation unit is built with -ffp-contract=off).  This
+//   Exact — one float32 rounding per reference op: IEEE division, tanh/exp/expm1 within ~1 ulp (tanh_rf, exp_rf,
+//           expm1_rf below), ocml logf, no FMA contraction (the translation unit is built with -ffp-contract=off).  This
 //           is the op order TensorFlow's CPU kernels execute for the reference graph.
 //   Fast  — v_rcp_f32 / v_exp_f32 / v_log_f32 based forms (FIBHIP_FAST), a few ulp per op.
 //
@@ -113,6 +113,62 @@ template <class F> FIB_DEV float vzip(float a, float b, F f) { return f(a, b); }
 // IEEE division at 3 instructions instead of the ~11 of the generic expansion.  Checked exhaustively
 // over all 2^23 significands for every constant of the three models (tools/ubench/divtest.c);
 // it can differ only when a/c is subnormal (by at most one subnormal ulp).
+// tanh for the rounding-faithful policy: branch-free, <= 1.4 ulp of the true tanh over the whole float32 range
+// (tools/ubench/tanh_test.c: 32 M samples; glibc's tanhf: 2.2 ulp, the float32 tanh TensorFlow's CPU kernels use is a
+// rational approximation of a few ulp too) at ~27 instructions and two transcendental issues, where ocml's tanhf
+// runs both of its divergent branches at ~4x that.
+//   |x| < 0.625:  x + x*z*P(z), z = x^2              (Cephes tanhf's polynomial)
+//   otherwise:    1 - 2/(e + 1), e = exp(2|x|) = 2^f * 2^n with log2(e) split in two terms and f in [-1/2, 1/2] on
+//                 v_exp_f32, the quotient by v_rcp_f32 + one Newton step
+static FIB_DEV float tanh_rf(float x)
+{
+    const float a = __builtin_fabsf(x);
+    const float z = a * a;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    const float small = __builtin_fmaf(p * z, a, a);
+    const float y = 2.0f * __builtin_fminf(a, 10.0f);                 // tanh(10) rounds to 1; keeps 2^n finite
+    constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.92596299112661746e-8f;
+    const float t = y * L2E_HI;
+    const float n = __builtin_rintf(t);
+    const float f = (__builtin_fmaf(y, L2E_HI, -t) + y * L2E_LO) + (t - n);
+    const float e = __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+    const float d = e + 1.0f;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    const float big = __builtin_fmaf(-2.0f, r, 1.0f);
+    const float res = !(a >= 0.625f) ? small : big;                  // (a NaN takes the polynomial and stays a NaN)
+    return __builtin_copysignf(res, x);
+}
+
+// exp and expm1 for the rounding-faithful policy, branch-free (tools/ubench/expm1_test.c, 50 M samples per sign):
+// exp <= 0.65 ulp (1.6 in the subnormal range), expm1 <= 1.25 ulp for x < 0 — the only sign a positive time constant
+// gives rush_larsen — and <= 2.5 ulp for x > 0; 12 and 22 instructions against ocml's 18 and 31.
+static FIB_DEV float exp_rf(float x)
+{
+    constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.92596299112661746e-8f;
+    x = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);        // 2^n stays finite; exp(89) is +inf already
+    const float t = x * L2E_HI;
+    const float n = __builtin_rintf(t);
+    const float f = (__builtin_fmaf(x, L2E_HI, -t) + x * L2E_LO) + (t - n);
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+static FIB_DEV float expm1_rf(float x)
+{
+    float p = 1.0f / 5040.0f;                                       // |x| < 0.35: Taylor to x^7 (truncation 2e-8)
+    p = __builtin_fmaf(p, x, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, x, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, x, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, x, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, x, 0.5f);
+    const float small = __builtin_fmaf(p * x, x, x);
+    const float big = exp_rf(x) - 1.0f;
+    return !(__builtin_fabsf(x) >= 0.35f) ? small : big;
+}
+
 struct Exact {
     // a*b + c: the reference rounds the product and the sum separately
     template <class T, class B, class C>
@@ -126,7 +182,7 @@ struct Exact {
         return vfma(r, rc, q);
     }
     template <class T>
-    static FIB_DEV T tanhv(const T &a) { return vmap(a, [](float x) { return tanhf(x); }); }
+    static FIB_DEV T tanhv(const T &a) { return vmap(a, [](float x) { return tanh_rf(x); }); }
     // 1 + tanh(a) and 0.5*(1 + tanh(a)) - s, as the reference writes them (fenton.py:83,90)
     template <class T>
     static FIB_DEV T one_plus_tanh(const T &a) { return 1.0f + tanhv(a); }
@@ -135,13 +191,13 @@ struct Exact {
     template <class A, class T>
     static FIB_DEV T div(const A &a, const T &b) { return vzip(a, b, [](float x, float y) { return x / y; }); }
     template <class T> static FIB_DEV T rcp(const T &a) { return vmap(a, [](float x) { return 1.0f / x; }); }
-    template <class T> static FIB_DEV T exp(const T &a) { return vmap(a, [](float x) { return expf(x); }); }
-    template <class T> static FIB_DEV T expm1(const T &a) { return vmap(a, [](float x) { return expm1f(x); }); }
+    template <class T> static FIB_DEV T exp(const T &a) { return vmap(a, [](float x) { return exp_rf(x); }); }
+    template <class T> static FIB_DEV T expm1(const T &a) { return vmap(a, [](float x) { return expm1_rf(x); }); }
     template <class T> static FIB_DEV T log(const T &a) { return vmap(a, [](float x) { return logf(x); }); }
     // generated code (traced models): division by an arbitrary constant stays a true IEEE division here
     template <class T> static FIB_DEV T divk(const T &a, float c) { return vmap(a, [c](float x) { return x / c; }); }
     template <class T> static FIB_DEV T expm1g(const T &a) { return expm1(a); }
-    static FIB_DEV float tanh(float a) { return tanhf(a); }   // == tanhv<float>
+    static FIB_DEV float tanh(float a) { return tanh_rf(a); }   // == tanhv<float>
     static FIB_DEV float sqrt(float a) { return sqrtf(a); }
 };
 
