@@ -21,7 +21,9 @@
 //   threads, so consecutive lanes touch consecutive LDS words for all nine taps (conflict-free for
 //   any tile shape) and every lane of every wave has work.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 #include "models.hpp"
 
 namespace fib {

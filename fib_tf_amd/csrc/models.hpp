@@ -18,8 +18,10 @@
 //
 // The formulas follow fenton.py:46-108, br.py:125-332 and court.py:124-429 (cited per block).
 #pragma once
+#ifndef __HIPCC_RTC__            // hiprtc (in-process builds of traced models) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#endif
 
 namespace fib {
 

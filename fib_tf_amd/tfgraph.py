@@ -169,7 +169,9 @@ def global_variables_initializer():
 def constant(value, dtype=None, shape=None, name=None):
     if _is_scalar(value):
         return _scalar(value)
-    return np.array(value, dtype=np.float32 if dtype is None else dtype)
+    if dtype is None or dtype == 1 or dtype is float32:       # (1 = TF's DT_FLOAT enum, fenton_simple.py:36)
+        dtype = np.float32
+    return np.array(value, dtype=dtype)
 
 
 _NP_UNARY = {'sign': np.sign, 'tanh': np.tanh, 'exp': np.exp, 'expm1': np.expm1, 'log': np.log, 'sqrt': np.sqrt,
@@ -264,9 +266,55 @@ def identity(t, name=None):
     return t
 
 
-def pad(*a, **k):
-    raise NotImplementedError('tfgraph: stencils are only available through IonicModel.enforce_boundary / '
-                              'IonicModel.laplace (the fused kernels implement exactly that 9-point stencil)')
+def pad(tensor, paddings=None, mode='CONSTANT', name=None, **k):
+    """the one pad a model file needs on its own: the no-flux boundary written out as the reference's
+    `enforce_boundary` writes it — `tf.pad(X[1:-1, 1:-1], [[1, 1], [1, 1]], 'SYMMETRIC')` (ionic.py:107-113,
+    fenton_simple.py:51-56).  It becomes the same graph node as IonicModel.enforce_boundary(X)."""
+    interior = (slice(1, -1, None), slice(1, -1, None))
+    ok = (isinstance(tensor, Tensor) and tensor.op == 'index' and tuple(tensor.attr) == interior
+          and paddings is not None and np.array_equal(np.asarray(paddings), [[1, 1], [1, 1]])
+          and str(mode).upper() == 'SYMMETRIC')
+    if not ok:
+        raise NotImplementedError('tfgraph: tf.pad is only understood as the no-flux boundary '
+                                  'tf.pad(X[1:-1, 1:-1], [[1, 1], [1, 1]], \'SYMMETRIC\'); other stencils are available '
+                                  'through IonicModel.enforce_boundary / IonicModel.laplace or a 3x3 tf.nn.depthwise_conv2d')
+    return Tensor('bnd', (tensor.args[0],))
+
+
+class _View4:
+    """a [H, W] tensor seen as [1, H, W, 1] (tf.expand_dims twice) — only as the argument and the result of the 3x3
+    convolution below"""
+
+    def __init__(self, base, axes):
+        self.base, self.axes = base, tuple(axes)
+
+    def __getitem__(self, idx):
+        if len(self.axes) == 2 and tuple(idx) == (0, slice(None), slice(None), 0):
+            return self.base
+        raise NotImplementedError('tfgraph: a [1, H, W, 1] view can only be sliced back with y[0, :, :, 0]')
+
+
+def expand_dims(x, axis=None, name=None, dim=None):
+    axis = dim if axis is None else axis
+    if isinstance(x, Tensor) and axis == 0:
+        return _View4(x, (0,))
+    if isinstance(x, _View4) and x.axes == (0,) and axis in (-1, 3):
+        return _View4(x.base, (0, -1))
+    raise NotImplementedError('tfgraph: tf.expand_dims is only understood as expand_dims(expand_dims(x, 0), -1), the '
+                              '[1, H, W, 1] view a 2-D convolution wants')
+
+
+class nn:
+    """tf.nn: the 3x3 depthwise convolution the stand-alone model scripts use as their Laplacian"""
+
+    @staticmethod
+    def depthwise_conv2d(input, filter, strides, padding, name=None, **k):       # noqa: A002  (TF's own names)
+        kern = np.asarray(filter, dtype=np.float32)
+        if not (isinstance(input, _View4) and input.axes == (0, -1) and kern.shape == (3, 3, 1, 1)
+                and list(strides) == [1, 1, 1, 1] and str(padding).upper() == 'SAME'):
+            raise NotImplementedError('tfgraph: tf.nn.depthwise_conv2d is only understood as a 3x3 single-channel '
+                                      'convolution of a [1, H, W, 1] view with stride 1 and padding \'SAME\'')
+        return _View4(Tensor('conv3', (input.base,), attr=tuple(float(v) for v in kern.reshape(9))), (0, -1))
 
 
 @contextlib.contextmanager

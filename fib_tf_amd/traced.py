@@ -140,8 +140,9 @@ class Level:
 class Program:
     """levels[k] = sub-step k of the op; mask = slots the op assigns"""
 
-    def __init__(self, levels, mask, uses_lap):
+    def __init__(self, levels, mask, uses_lap, zeropad=False):
         self.levels, self.mask, self.uses_lap = levels, mask, uses_lap
+        self.zeropad = zeropad            # the Laplacian is the zero-padded 3x3 convolution (fenton_simple.py:38-49)
 
 
 def _walk(expr, seen, visit):
@@ -308,21 +309,34 @@ class Compiler:
         return self._finish(levels, mask)
 
     def _finish(self, levels, mask):
-        uses_lap = False
+        uses_lap = zeropad = False
         for lv in levels:
             for e in lv.outs.values():
                 found = []
-                _walk(e, set(), lambda n: found.append(n) if n.op in ('lap', 'bnd') else None)
+                _walk(e, set(), lambda n: found.append(n) if n.op in ('lap', 'bnd', 'conv3') else None)
                 for n in found:
                     self._note_pot(n, lv)
-                    uses_lap = uses_lap or n.op == 'lap'
-        return Program(levels, mask, uses_lap)
+                    uses_lap = uses_lap or n.op in ('lap', 'conv3')
+                    zeropad = zeropad or n.op == 'conv3'
+                    if n.op == 'lap' and zeropad or n.op == 'conv3' and any(m.op == 'lap' for m in found):
+                        raise TraceError('a model uses ONE Laplacian: IonicModel.laplace or the 3x3 convolution, not both')
+        return Program(levels, mask, uses_lap, zeropad)
 
     pot_slot = None
 
     def _note_pot(self, node, lv):
         arg = node.args[0]
-        if node.op == 'lap':
+        if node.op == 'conv3':
+            # the zero-padded 3x3 convolution of the stand-alone scripts (fenton_simple.py:38-49): the kernels carry
+            # exactly one such stencil, the Laplacian [[.5, 1, .5], [1, -6, 1], [.5, 1, .5]] of an enforced array
+            if tuple(node.attr) != (0.5, 1.0, 0.5, 1.0, -6.0, 1.0, 0.5, 1.0, 0.5):
+                raise TraceError('tf.nn.depthwise_conv2d: the only 3x3 kernel the fused kernels implement is the '
+                                 'Laplacian [[.5, 1, .5], [1, -6, 1], [.5, 1, .5]] (fenton_simple.py:46-48)')
+            if not (isinstance(arg, Tensor) and arg.op == 'bnd'):
+                raise TraceError('the 3x3 convolution must be applied to the boundary-enforced array '
+                                 '(enforce_boundary(X), fenton_simple.py:131-135)')
+            arg = arg.args[0]
+        elif node.op == 'lap':
             if not (isinstance(arg, Tensor) and arg.op == 'bnd'):
                 raise TraceError('self.laplace(X): X must be self.enforce_boundary(state variable) — the fused kernel '
                                  'implements the stencil with the no-flux boundary folded in (ionic.py:44-60,107-113)')
@@ -528,7 +542,7 @@ class _Emitter:
             r = self.slot_expr(node)
         elif op == 'bnd':
             r = 'V0'
-        elif op == 'lap':
+        elif op in ('lap', 'conv3'):
             r = 'lap'
         elif op in _BINOPS:
             special = self._heaviside(node) if op == 'mul' else self._fused(node)
@@ -595,7 +609,7 @@ def _weight(level):
     total = [0]
 
     def visit(node):
-        if node.op not in ('param', 'var', 'bnd', 'lap'):
+        if node.op not in ('param', 'var', 'bnd', 'lap', 'conv3'):
             total[0] += 4 if node.op in _HEAVY else 1
     seen = set()
     for e in level.outs.values():
@@ -609,7 +623,9 @@ def generate(programs, nslots, remap, spt):
     n = nslots
     tick = programs[0]
     K = len(tick.levels)
-    fuse = 1 < K <= 12 and K == spt
+    zeropad = any(getattr(p, 'zeropad', False) for p in programs)
+    # (the zero-padded tap rule lives in tick_kernel only: such a model runs one sub-step per launch)
+    fuse = 1 < K <= 12 and K == spt and not zeropad
     R = 3 if n <= 5 else 2
     TX, TY = 64 - 2 * K, 16 * R - 2 * K
     if fuse and (TX < 16 or TY < 6):
@@ -638,7 +654,9 @@ def generate(programs, nslots, remap, spt):
            '    static constexpr int NVAR = %d;' % n,
            '    static constexpr int DEFAULT_STEPS = %d;' % spt,
            '    static constexpr int NMODES = %d;' % len(programs),
-           '    static constexpr bool HAS_VEC = true;',
+           '    static constexpr bool HAS_VEC = true;'] + (
+           ['    static constexpr bool ZEROPAD = true;    // taps outside the grid read 0 (3x3 convolution, padding SAME)']
+           if zeropad else []) + [
            '    struct Consts { float unused; };',
            '    template <class C> static FIB_DEV const C &pinned(const C &k) { return k; }',
            '    static constexpr unsigned mask(int mode)', '    {']

@@ -31,6 +31,20 @@ def laplace(X0, phase=None):
     return L.astype(f32)
 
 
+def conv3_same(X0, k9):
+    """tf.nn.depthwise_conv2d of one channel with a 3x3 kernel, stride 1, padding 'SAME' (zeros outside the array;
+    fenton_simple.py:38-49).  TensorFlow does not specify its accumulation order: this is row-major over the kernel,
+    one float32 rounding per product and per sum — the order tests/golden/_standin and the device kernel use."""
+    X = np.pad(np.asarray(X0, f32), 1, mode='constant')
+    H, W = X0.shape
+    acc = None
+    for i in range(3):
+        for j in range(3):
+            term = (f32(k9[3 * i + j]) * X[i:i + H, j:j + W]).astype(f32)
+            acc = term if acc is None else (acc + term).astype(f32)
+    return acc
+
+
 def _c(x):
     return x if isinstance(x, np.ndarray) else f32(x)
 
@@ -66,6 +80,8 @@ class Interpreter:
             r = enforce_boundary(ev(a[0]))
         elif op == 'lap':
             r = laplace(ev(a[0]), self.phase)
+        elif op == 'conv3':
+            r = conv3_same(ev(a[0]), node.attr)
         elif op in _BIN:
             r = _BIN[op](_c(ev(a[0])), _c(ev(a[1])))
         elif op in _UN:

@@ -103,6 +103,38 @@ def test_generated_four_variable_equals_handwritten(gpu_lib, golden, fixture):
                 assert np.array_equal(got, nat.get_state(-1)), 'generated vs hand-written kernel differ at tick %d' % t
 
 
+def test_generated_conv_variant_equals_handwritten(gpu_lib, golden):
+    """tests/models/simple_conv.py — the boundary as `tf.pad`, the Laplacian as a zero-padded 3x3
+    `tf.nn.depthwise_conv2d` — -> generated kernel (ZEROPAD, one sub-step per launch), against the golden trajectory
+    of the reference's fenton_simple.py and, under the rounding-faithful policy, BITWISE against the hand-written
+    FIBHIP_ZEROPAD kernel"""
+    from fib_tf_amd import _lib
+    f = golden('fenton_simple_traj')
+    names = ('U', 'V', 'W', 'S')
+    init = _golden_init(f, names)
+    _, H, W = init.shape
+    for fast in (False, True):
+        m = make_model('fvc', H, W, fast_math=fast, diff=float(f['diff']))
+        m.define()
+        m._ensure_compiled()
+        assert m.VAR_NAMES == names and m._stepper.launch_plan() == (1, 1)
+        assert 'ZEROPAD = true' in m.generated_source()
+        m._stepper.set_state(-1, init)
+        nat = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, float(f['diff']), flags=_lib.ZEROPAD | (_lib.FAST if fast else 0),
+                           steps_per_tick=1)
+        nat.set_state(-1, init)
+        t0 = 0
+        for t in [1, 2, 10, 100]:                           # (the script's own S2 fires at step 150)
+            m._stepper.step(t - t0)
+            nat.step(t - t0)
+            t0 = t
+            got = m._stepper.get_state(-1)
+            for i, n in enumerate(names):
+                _close(got[i], f['%s_t%d' % (n, t)], 2e-5 if not fast else 2e-4, 'fvc %s t%d' % (n, t), 1.0)
+            if not fast:
+                assert np.array_equal(got, nat.get_state(-1)), 'generated vs hand-written ZEROPAD kernel differ at step %d' % t
+
+
 def test_generated_eight_variable_vs_handwritten(gpu_lib, golden):
     """tests/models/eight_variable.py -> generated kernel, against the golden trajectory of the reference's br.py
     (direct gates) and the hand-written Beeler-Reuter kernel.  The hand-written kernel folds a few constants

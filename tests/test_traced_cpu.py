@@ -211,6 +211,54 @@ def test_own_model_files_reproduce_reference_golden(clean_modules, golden, name,
         check(st, f, m.VAR_NAMES, t, tol, scales)
 
 
+def test_conv_laplacian_model_reproduces_fenton_simple_golden(clean_modules, golden):
+    """tests/models/simple_conv.py (tf.pad boundary + zero-padded 3x3 tf.nn.depthwise_conv2d, our own file in the style
+    of the reference's stand-alone scripts) -> graph -> interpreter reproduces the golden trajectory generated from the
+    reference's own fenton_simple.py; the generated source marks the model ZEROPAD and keeps one sub-step per launch"""
+    sys.path.insert(0, HERE)
+    from traced_cases import make_model
+    from oracle.graph_eval import Interpreter
+    import fib_tf_amd.tfgraph as tf
+    from fib_tf_amd.traced import TraceError
+    f = golden('fenton_simple_traj')
+    H, W = f['init_U'].shape
+    m = make_model('fvc', H, W, diff=float(f['diff']))
+    m.define()
+    c = m._analyze()
+    assert c['spt'] == 1 and c['programs'][0][1].zeropad and c['programs'][0][1].uses_lap
+    assert 'static constexpr bool ZEROPAD = true;' in c['source'] and '#define FIB_CUSTOM_K 1' in c['source']
+    it = Interpreter(c, None)
+    st = state_of(f, m.VAR_NAMES)
+    t0 = 0
+    for t in [1, 2, 10, 100]:                               # (the script's S2 fires at step 150)
+        st = it.tick(st, t - t0)
+        t0 = t
+        check(st, f, m.VAR_NAMES, t, 1e-6)
+    # what the tracer does not take for a stencil it refuses by name
+    x = tf.Variable(np.zeros((8, 8)))
+    with pytest.raises(NotImplementedError, match='no-flux boundary'):
+        tf.pad(x, [[1, 1], [1, 1]], 'REFLECT')
+    with pytest.raises(NotImplementedError, match='3x3 single-channel'):
+        tf.nn.depthwise_conv2d(tf.expand_dims(tf.expand_dims(x, 0), -1), np.ones((5, 5, 1, 1)), [1, 1, 1, 1], 'SAME')
+    bad = tf.nn.depthwise_conv2d(tf.expand_dims(tf.expand_dims(tf.pad(x[1:-1, 1:-1], [[1, 1], [1, 1]], 'SYMMETRIC'), 0), -1),
+                                 np.ones((3, 3, 1, 1)), [1, 1, 1, 1], 'SAME')[0, :, :, 0]
+    from fib_tf_amd.traced import IonicModel
+
+    class M(IonicModel):
+        def define(self):
+            super().define()
+            v = tf.Variable(np.zeros([16, 16], np.float32))
+            self._ode_op = tf.group(v.assign(self.solve((v,))[0]))
+    M.solve = lambda self, s: (s[0] + tf.nn.depthwise_conv2d(
+        tf.expand_dims(tf.expand_dims(tf.pad(s[0][1:-1, 1:-1], [[1, 1], [1, 1]], 'SYMMETRIC'), 0), -1),
+        np.ones((3, 3, 1, 1)), [1, 1, 1, 1], 'SAME')[0, :, :, 0],)
+    mm = M({'height': 16, 'width': 16, 'dt': 0.1, 'diff': 1.0, 'duration': 1, 'dt_per_plot': 1})
+    mm.define()
+    with pytest.raises(TraceError, match='only 3x3 kernel'):
+        mm.generated_source()
+    del bad
+
+
 @pytest.mark.parametrize('name,spt,kinds', [('ap', 10, 1), ('ms', 5, 1), ('gated', 1, 1), ('mrfhn', 4, 2)])
 def test_test_models_trace_and_interpret(clean_modules, name, spt, kinds):
     sys.path.insert(0, HERE)
@@ -258,7 +306,7 @@ def test_tracer_refuses_what_it_cannot_compile(clean_modules):
     with pytest.raises(TraceError, match='outside solve'):
         model(lambda self, s: (s[0] * 2.0,), post=lambda o: (o[0] + 1.0,)).generated_source()
     with pytest.raises(NotImplementedError, match='IonicModel.enforce_boundary'):
-        tf.pad(None, None)
+        tf.pad(None, None)                    # (the one pad that IS understood: test_conv_laplacian_model_...)
     m = model(lambda self, s: (s[0] * 2.0,))
     m._ode_op = None
     with pytest.raises(TraceError, match='_ode_op'):

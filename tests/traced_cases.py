@@ -17,6 +17,8 @@ MODELS = {
     # our own transcriptions of the two published models the hand-written kernels implement: generated vs hand-written
     'fv': ('four_variable', 'FourVariable', True, 0.1, 1.5, 1.0),
     'ev': ('eight_variable', 'EightVariable', True, 0.1, 0.809, 10.0),
+    # the same model with the boundary as tf.pad and the Laplacian as a zero-padded 3x3 tf.nn.depthwise_conv2d
+    'fvc': ('simple_conv', 'FourVariableConv', True, 0.1, 1.5, 1.0),
 }
 
 
