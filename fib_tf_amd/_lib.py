@@ -33,7 +33,19 @@ class Desc(C.Structure):
                 ('dt', C.c_double), ('diff', C.c_double), ('flags', C.c_uint), ('device', C.c_int),
                 ('steps_per_tick', C.c_int), ('global_height', C.c_int), ('row_offset', C.c_int),
                 ('ghost_top', C.c_int), ('ghost_bottom', C.c_int), ('stream', C.c_void_p),
-                ('ext_slab', C.c_void_p * 2)]
+                ('ext_slab', C.c_void_p * 2), ('module', C.c_void_p)]
+
+
+class ModuleKernel(C.Structure):
+    _fields_ = [('symbol', C.c_char_p), ('kind', C.c_int), ('mode', C.c_int), ('fast', C.c_int), ('phase', C.c_int),
+                ('K', C.c_int), ('TX', C.c_int), ('TY', C.c_int), ('NT', C.c_int)]
+
+
+class ModuleDesc(C.Structure):
+    _fields_ = [('struct_size', C.c_int), ('nvar', C.c_int), ('steps_per_tick', C.c_int), ('nmodes', C.c_int),
+                ('masks', C.c_uint * 8), ('consts_bytes', C.c_int)] + [
+                    (k, C.c_int) for k in ('K', 'TX', 'TY', 'R', 'TYB', 'K2', 'TX2', 'TY2', 'R2')] + [
+                    ('nkernels', C.c_int), ('kernels', C.POINTER(ModuleKernel))]
 
 
 class HaloMsg(C.Structure):
@@ -83,6 +95,8 @@ SYMBOLS = {
     'fibhip_comm_exchange': ([_h, C.c_int, C.c_int], C.c_int),
     'fibhip_comm_free': ([_h], C.c_int),
     'fibhip_copy_bandwidth': ([C.c_int, C.c_size_t, C.c_int, _fp], C.c_int),
+    'fibhip_module_load': ([C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ModuleDesc), C.POINTER(C.c_void_p)], C.c_int),
+    'fibhip_module_unload': ([C.c_void_p], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -159,6 +173,114 @@ def lib():
     return _lib
 
 
+# ---- in-process builds of traced models: hiprtc -> code object -> fibhip_module_load ------------------------------
+HIPRTC = os.environ.get('FIBTF_HIPRTC', '/opt/rocm/lib/libhiprtc.so')
+_rtc = None
+
+
+def hiprtc():
+    """libhiprtc bound through ctypes, or None when the runtime does not ship it"""
+    global _rtc
+    if _rtc is None:
+        try:
+            R = C.CDLL(HIPRTC)
+        except OSError:
+            _rtc = False
+            return None
+        pp = C.POINTER(C.c_char_p)
+        R.hiprtcCreateProgram.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, pp, pp]
+        R.hiprtcAddNameExpression.argtypes = [C.c_void_p, C.c_char_p]
+        R.hiprtcCompileProgram.argtypes = [C.c_void_p, C.c_int, pp]
+        R.hiprtcGetLoweredName.argtypes = [C.c_void_p, C.c_char_p, pp]
+        R.hiprtcGetProgramLogSize.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        R.hiprtcGetProgramLog.argtypes = [C.c_void_p, C.c_char_p]
+        R.hiprtcGetCodeSize.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        R.hiprtcGetCode.argtypes = [C.c_void_p, C.c_char_p]
+        R.hiprtcDestroyProgram.argtypes = [C.POINTER(C.c_void_p)]
+        _rtc = R
+    return _rtc or None
+
+
+def rtc_compile(source, headers, name_exprs, options):
+    """compile device code in this process: (code object bytes, {name expression: lowered symbol}).
+    headers: {include name: text} handed over in memory; hiprtc needs no GPU (gfx950 is an option)."""
+    R = hiprtc()
+    if R is None:
+        raise FibhipError('libhiprtc is not available (%s)' % HIPRTC)
+    prog = C.c_void_p()
+    names = list(headers)
+    harr = (C.c_char_p * len(names))(*[headers[n].encode() for n in names])
+    narr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    rc = R.hiprtcCreateProgram(C.byref(prog), source.encode(), b'fibhip_traced.hip', len(names), harr, narr)
+    if rc:
+        raise FibhipError('hiprtcCreateProgram failed (%d)' % rc)
+    try:
+        for e in name_exprs:
+            if R.hiprtcAddNameExpression(prog, e.encode()):
+                raise FibhipError('hiprtcAddNameExpression refused %r' % e)
+        oarr = (C.c_char_p * len(options))(*[o.encode() for o in options])
+        rc = R.hiprtcCompileProgram(prog, len(options), oarr)
+        if rc:
+            n = C.c_size_t()
+            R.hiprtcGetProgramLogSize(prog, C.byref(n))
+            log = C.create_string_buffer(max(1, n.value))
+            R.hiprtcGetProgramLog(prog, log)
+            raise FibhipError('hiprtc could not compile the generated model (%d):\n%s' % (rc, log.value.decode('utf-8', 'replace')[-4000:]))
+        lowered = {}
+        for e in name_exprs:
+            p = C.c_char_p()
+            if R.hiprtcGetLoweredName(prog, e.encode(), C.byref(p)) or not p.value:
+                raise FibhipError('hiprtcGetLoweredName failed for %r' % e)
+            lowered[e] = p.value.decode()
+        n = C.c_size_t()
+        R.hiprtcGetCodeSize(prog, C.byref(n))
+        code = C.create_string_buffer(n.value)
+        R.hiprtcGetCode(prog, code)
+        return code.raw, lowered
+    finally:
+        R.hiprtcDestroyProgram(C.byref(prog))
+
+
+RTC_OPTIONS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-slp-vectorize', '-std=c++17',
+               '-I' + os.path.join(HERE, 'csrc')]
+
+
+class ModuleLibrary:
+    """the stock library + ONE traced model's code object loaded into it (fibhip_module_load): stands where a
+    per-model build of libfibhip stood — `Stepper(..., library=this)` creates FIBHIP_CUSTOM handles on the module"""
+
+    def __init__(self, code, meta, device, name):
+        L = lib()
+        self._L, self._code, self.meta, self.device = L, code, meta, device
+        self._name = '%s#module:%s' % (SO, name)
+        kern = (ModuleKernel * len(meta['kernels']))()
+        self._keep = []
+        for i, k in enumerate(meta['kernels']):
+            sym = k['symbol'].encode()
+            self._keep.append(sym)
+            kern[i] = ModuleKernel(sym, k['kind'], k['mode'], k['fast'], k['phase'], k['K'], k['TX'], k['TY'], k['NT'])
+        d = ModuleDesc()
+        d.struct_size = C.sizeof(ModuleDesc)
+        d.nvar, d.steps_per_tick, d.nmodes, d.consts_bytes = meta['nvar'], meta['spt'], meta['nmodes'], meta['consts_bytes']
+        for i, m in enumerate(meta['masks']):
+            d.masks[i] = m
+        for k in ('K', 'TX', 'TY', 'R', 'TYB', 'K2', 'TX2', 'TY2', 'R2'):
+            setattr(d, k, meta['plan'][k])
+        d.nkernels, d.kernels = len(kern), kern
+        self.module = C.c_void_p()
+        check(L.fibhip_module_load(device, code, len(code), C.byref(d), C.byref(self.module)), L)
+
+    # model facts the stock library cannot know
+    def fibhip_nvar(self, model):
+        return self.meta['nvar'] if model == CUSTOM else self._L.fibhip_nvar(model)
+
+    def fibhip_default_steps_per_tick(self, model):
+        return self.meta['spt'] if model == CUSTOM else self._L.fibhip_default_steps_per_tick(model)
+
+    def __getattr__(self, name):
+        return getattr(self._L, name)
+
+
 def check(rc, L=None):
     if rc < 0:
         raise FibhipError((L or lib()).fibhip_last_error().decode('utf-8', 'replace'))
@@ -226,6 +348,7 @@ class Stepper:
         d.stream = stream
         if ext_slabs is not None:
             d.ext_slab[0], d.ext_slab[1] = ext_slabs
+        d.module = getattr(L, 'module', None)          # a traced model's run-time module (ModuleLibrary), or NULL
         self._h = _h()
         self._L = L
         self.nvar = self._ck(L.fibhip_nvar(model))

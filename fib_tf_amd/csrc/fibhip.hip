@@ -55,6 +55,9 @@ struct LaunchCtx {
     PhaseTab ph;
     const void *consts;
     int sub0;
+    // a kernel of a code object loaded at run time (fibhip_module_load) instead of one linked into this library
+    hipFunction_t kern;
+    int kind, K, TX, TY, NT, nvar, consts_bytes;
 };
 
 typedef hipError_t (*launch_fn)(hipStream_t, const LaunchCtx &);
@@ -137,12 +140,57 @@ static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
     return hipGetLastError();
 }
 
+// One launcher for every kernel of a run-time module (a traced model compiled in-process by hiprtc): the same grids
+// as launch_tick / launch_strip / launch_pointwise, the kernel arguments laid out by hand as the compiler lays out
+// (Geo, PtrTab<NVAR>, PhaseTab, Consts, int) — every argument at its natural alignment, in order.
+enum { MK_TICK = 0, MK_STRIP = 1, MK_POINTWISE = 2 };
+static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
+{
+    Geo g = c.g;
+    int threads, grid;
+    if (c.kind == MK_POINTWISE) {
+        const long n = (long)(g.r1 - g.r0) * g.W;
+        if (n <= 0) return hipSuccess;
+        threads = 256;
+        grid = (int)((n + 255) / 256);
+    } else {
+        g.tiles_x = (g.W + c.TX - 1) / c.TX;
+        g.ty_a = (g.r1 > g.r0) ? (g.r1 - g.r0 + c.TY - 1) / c.TY : 0;
+        const int tiles_y = g.ty_a + ((g.rb1 > g.rb0) ? (g.rb1 - g.rb0 + c.TY - 1) / c.TY : 0);
+        g.ntiles = g.tiles_x * tiles_y;
+        if (g.ntiles <= 0) return hipSuccess;
+        threads = c.kind == MK_TICK ? c.NT : 64 * ((c.TY + 2 * (c.K - 1) + (-c.NT) - 1) / (-c.NT));
+        grid = ((g.ntiles + 7) / 8) * 8;
+    }
+    alignas(8) char buf[sizeof(Geo) + 8 + 2 * FIB_MAXVAR * sizeof(void *) + sizeof(PhaseTab) + 64 + 16];
+    size_t off = 0;
+    auto put = [&](const void *p, size_t n, size_t align) {
+        off = (off + align - 1) & ~(align - 1);
+        memcpy(buf + off, p, n);
+        off += n;
+    };
+    put(&g, sizeof g, alignof(Geo));
+    off = (off + 7) & ~(size_t)7;                                   // PtrTab<NVAR>: in[NVAR] then out[NVAR]
+    memcpy(buf + off, c.in, (size_t)c.nvar * sizeof(void *));
+    off += (size_t)c.nvar * sizeof(void *);
+    memcpy(buf + off, c.out, (size_t)c.nvar * sizeof(void *));
+    off += (size_t)c.nvar * sizeof(void *);
+    if (c.kind != MK_POINTWISE) put(&c.ph, sizeof c.ph, alignof(PhaseTab));
+    const char zeros[64] = {0};
+    if (c.consts_bytes > 0) put(c.consts ? c.consts : zeros, (size_t)c.consts_bytes, 4);
+    if (c.kind != MK_POINTWISE) put(&c.sub0, sizeof c.sub0, alignof(int));
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &off, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(c.kern, grid, 1, 1, threads, 1, 1, 0, st, nullptr, config);
+}
+
 constexpr int VM_FENTON_ZP = 100;   // variant-table id of FentonZP (not a fibhip_model: selected by FIBHIP_ZEROPAD)
 
 struct Variant {
     int model, mode, fast, phase;
     int K, TX, TY, NT;
     launch_fn fn;
+    hipFunction_t kern = nullptr;   // run-time module kernels only (fn == launch_module)
+    int kind = 0;
 };
 
 #define V4(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
@@ -270,6 +318,17 @@ struct PlanItem {
     int K;
     launch_fn fn;
     int TY, TX;
+    const Variant *v = nullptr;     // the table entry it came from (run-time module kernels carry their launch data there)
+};
+
+// a traced model's device code loaded at run time (fibhip_module_load)
+struct fibhip_module {
+    hipModule_t mod = nullptr;
+    int device = 0;
+    int nvar = 0, spt = 1, nmodes = 1, consts_bytes = 4;
+    unsigned masks[8] = {0};
+    int K = 1, TX = 64, TY = 4, R = 3, TYB = 0, K2 = 1, TX2 = 64, TY2 = 4, R2 = 4;   // plan hints of the generated header
+    std::vector<Variant> variants;
 };
 
 struct fibhip_ctx {
@@ -301,6 +360,7 @@ struct fibhip_ctx {
     int own0, own1;         // owned local rows
     bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
     bool pending;           // fibhip_step's last tick has not been launched yet (see lazy_fusable)
+    fibhip_module *mod;     // FIBHIP_CUSTOM on a run-time module (fibhip_module_load), or null
     bool tuned;             // the plan has been checked against the other tile shapes on this very geometry (autotune)
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
@@ -312,6 +372,7 @@ struct fibhip_ctx {
 
 static const void *consts_of(fibhip_ctx *h)
 {
+    if (h->mod) return nullptr;                    // generated models carry their constants as literals
     switch (h->d.model) {
     case FIBHIP_FENTON4V: return &h->kf;
     case FIBHIP_BR: return &h->kb;
@@ -365,8 +426,11 @@ static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /
     if (mode < 0) mode = h->mode;
     // fenton_simple.py's Laplacian is a property of the kernel's model type (FentonZP): its own rows of the table
     const int vmodel = (h->d.model == FIBHIP_FENTON4V && (h->d.flags & FIBHIP_ZEROPAD)) ? VM_FENTON_ZP : h->d.model;
-    for (int i = 0; i < g_nvariants; ++i) {
-        const Variant &v = g_variants[i];
+    const Variant *tab = h->mod ? h->mod->variants.data() : g_variants;
+    const int ntab = h->mod ? (int)h->mod->variants.size() : g_nvariants;
+    for (int i = 0; i < ntab; ++i) {
+        const Variant &v = tab[i];
+        if (v.kind == MK_POINTWISE) continue;
         if (v.model != vmodel || v.mode != mode || v.fast != fast || v.phase != phase || v.K != K) continue;
         if (want && (v.TX != want[0] || v.TY != want[1] || v.NT != want[2])) continue;
         return &v;
@@ -398,6 +462,19 @@ static int build_plan(fibhip_ctx *h)
         // smaller rim when there are many tiles per CU (throughput-bound), fatter waves when there are
         // very many (occupancy).
         prefK = 1;
+        if (h->mod) {
+            // the same rule as the FIB_CUSTOM_* block below, with the generated header's numbers at run time
+            const fibhip_module &m = *h->mod;
+            const int ext = (h->cycle - 1) * h->spt;
+            const int rows = (h->own1 - h->own0) + (h->d.ghost_top ? ext : 0) + (h->d.ghost_bottom ? ext : 0);
+            const long tiles = (long)((h->d.width + m.TX - 1) / m.TX) * ((rows + m.TY - 1) / m.TY);
+            prefK = tiles <= (m.K2 > 1 ? 256 : 512) ? m.K : m.K2;
+            if (m.TYB > 0 && prefK == m.K && prefK > 1) {
+                const long tiles_b = (long)((h->d.width + m.TX - 1) / m.TX) * ((rows + m.TYB - 1) / m.TYB);
+                want[0] = m.TX; want[1] = tiles_b <= 256 ? m.TYB : m.TY; want[2] = -m.R;
+                nwant = 1;
+            }
+        }
 #ifdef FIB_CUSTOM_MODEL_INC
         if (h->d.model == FIBHIP_CUSTOM) {
             // one tile per CU or two: latency-bound, fuse the whole tick; more: throughput-bound (see the generator)
@@ -482,7 +559,7 @@ static int build_plan(fibhip_ctx *h)
             if (!best && nwant) best = find_variant(h, K, nullptr);
         }
         if (!best) return fail(FIBHIP_EINVAL, "no kernel variant for model %d mode %d", h->d.model, h->mode);
-        h->plan.push_back({best->K, best->fn, best->TY, best->TX});
+        h->plan.push_back({best->K, best->fn, best->TY, best->TX, best});
         rem -= best->K;
     }
     // Courtemanche: the reference's driver fires 'slow' right after every 10th tick (court.py:612-617).  When the
@@ -521,7 +598,11 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     if (desc->struct_size != (int)sizeof(fibhip_desc))
         return fail(FIBHIP_EINVAL, "fibhip_desc size mismatch: caller %d, library %d", desc->struct_size,
                     (int)sizeof(fibhip_desc));
-    const int nv = fibhip_nvar(desc->model);
+    fibhip_module *mod = (fibhip_module *)desc->module;
+    if (mod && desc->model != FIBHIP_CUSTOM) return fail(FIBHIP_EINVAL, "a run-time module serves FIBHIP_CUSTOM only");
+    if (mod && mod->device != desc->device)
+        return fail(FIBHIP_EINVAL, "the module was loaded on device %d, the handle asks for device %d", mod->device, desc->device);
+    const int nv = mod ? mod->nvar : fibhip_nvar(desc->model);
     if (nv < 0) return nv;
     const int Hg = desc->global_height ? desc->global_height : desc->height;
     if (desc->height < 3 || desc->width < 3 || Hg < 3)
@@ -549,7 +630,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->d = *desc;
     h->d.global_height = Hg;
     h->nvar = nv;
-    h->spt = desc->steps_per_tick > 0 ? desc->steps_per_tick : fibhip_default_steps_per_tick(desc->model);
+    h->mod = mod;
+    h->spt = desc->steps_per_tick > 0 ? desc->steps_per_tick : (mod ? mod->spt : fibhip_default_steps_per_tick(desc->model));
     h->cells = (size_t)desc->height * desc->width;
     const bool interleaved = (desc->flags & FIBHIP_ROW_INTERLEAVED) != 0;
     h->pitch = interleaved ? nv * desc->width : desc->width;
@@ -789,6 +871,7 @@ extern "C" int fibhip_set_consts(fibhip_t h, const float *tbl, int n)
 // which variables the tick op of this handle assigns (M::mask(mode))
 static unsigned tick_mask(const fibhip_ctx *h)
 {
+    if (h->mod) return h->mod->masks[h->mode];
     switch (h->d.model) {
     case FIBHIP_FENTON4V: return Fenton::mask(h->mode);
     case FIBHIP_BR: return BeelerReuter::mask(h->mode);
@@ -830,6 +913,13 @@ static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, Launc
     c.g.r1 = r1 > r0 ? r1 : r0;
     c.g.rb0 = rb0;
     c.g.rb1 = rb1 > rb0 ? rb1 : rb0;
+    if (it.v && it.v->kern) {                                     // a kernel of a run-time module
+        c.kern = it.v->kern;
+        c.kind = it.v->kind;
+        c.K = it.v->K; c.TX = it.v->TX; c.TY = it.v->TY; c.NT = it.v->NT;
+        c.nvar = h->nvar;
+        c.consts_bytes = h->mod ? h->mod->consts_bytes : 0;
+    }
     HIPCHK(it.fn(st, c));
     h->launches++;
     return 0;
@@ -913,7 +1003,7 @@ static int autotune(fibhip_ctx *h)
             const bool strip = v.NT < 0 && v.NT > -32 && v.K >= 2, single = v.NT > 0 && v.K == 1;
             if (!(strip || single) || h->spt % v.K != 0 || v.K > maxghost) continue;
             if (!heuristic.empty() && heuristic[0].fn == v.fn && heuristic_timed) continue;
-            for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX});
+            for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX, &v});
         }
         if (trial.empty()) continue;
         h->plan = trial;
@@ -1097,10 +1187,17 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
 }
 
 // re-evaluation of the model on the current state, in place, without the stencil: assigns mask(mode)
-static int run_pointwise_mode(fibhip_t h, launch_fn fn)
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr)
 {
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_mode inside an open tick");
     LaunchCtx c;
+    if (mv) {                                             // a pointwise kernel of a run-time module
+        c.kern = mv->kern;
+        c.kind = MK_POINTWISE;
+        c.K = 1; c.TX = c.TY = c.NT = 0;
+        c.nvar = h->nvar;
+        c.consts_bytes = h->mod->consts_bytes;
+    }
     for (int v = 0; v < h->nvar; ++v) {
         c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;
         c.out[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;   // in place
@@ -1135,6 +1232,13 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
     NEED(h);
     const bool fast = (h->d.flags & FIBHIP_FAST) != 0;
     (void)fast;
+    if (h->mod) {
+        FLUSH(h);
+        for (const Variant &v : h->mod->variants)
+            if (v.kind == MK_POINTWISE && v.mode == mode && v.fast == (fast ? 1 : 0) && mode >= 1)
+                return run_pointwise_mode(h, launch_module, &v);
+        return fail(FIBHIP_EINVAL, "step_mode: the traced model has no mode %d", mode);
+    }
 #ifdef FIB_CUSTOM_MODEL_INC
     if (h->d.model == FIBHIP_CUSTOM) {
         FLUSH(h);
@@ -1473,6 +1577,66 @@ extern "C" int fibhip_comm_free(fibhip_t h)
         g_rccl.CommDestroy(h->comm);
     }
     h->comm = nullptr;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// run-time modules: the device code of ONE traced model, compiled in-process by the caller (hiprtc), loaded here and
+// launched through the module API by the same host logic that drives the built-in models
+// ------------------------------------------------------------------------------------------
+extern "C" int fibhip_module_load(int device, const void *code, size_t nbytes, const fibhip_module_desc *d, fibhip_module_t *out)
+{
+    if (!code || !nbytes || !d || !out) return fail(FIBHIP_EINVAL, "module_load: null argument");
+    if (d->struct_size != (int)sizeof(fibhip_module_desc))
+        return fail(FIBHIP_EINVAL, "fibhip_module_desc size mismatch: caller %d, library %d", d->struct_size, (int)sizeof(fibhip_module_desc));
+    if (d->nvar < 1 || d->nvar > FIB_MAXVAR || d->nmodes < 1 || d->nmodes > 8 || d->steps_per_tick < 1 || d->consts_bytes < 0 ||
+        d->consts_bytes > 64 || d->nkernels < 1 || !d->kernels)
+        return fail(FIBHIP_EINVAL, "module_load: inconsistent description");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FIBHIP_EINVAL, "device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    fibhip_module *m = new (std::nothrow) fibhip_module();
+    if (!m) return fail(FIBHIP_ENOMEM, "out of host memory");
+    m->device = device;
+    m->nvar = d->nvar; m->spt = d->steps_per_tick; m->nmodes = d->nmodes; m->consts_bytes = d->consts_bytes;
+    for (int i = 0; i < 8; ++i) m->masks[i] = d->masks[i];
+    m->K = d->K; m->TX = d->TX; m->TY = d->TY; m->R = d->R; m->TYB = d->TYB;
+    m->K2 = d->K2; m->TX2 = d->TX2; m->TY2 = d->TY2; m->R2 = d->R2;
+    if (hipModuleLoadData(&m->mod, code) != hipSuccess) {
+        delete m;
+        return fail(FIBHIP_EHIP, "module_load: hipModuleLoadData refused the code object");
+    }
+    for (int i = 0; i < d->nkernels; ++i) {
+        const fibhip_module_kernel &k = d->kernels[i];
+        Variant v;
+        v.model = FIBHIP_CUSTOM; v.mode = k.mode; v.fast = k.fast; v.phase = k.phase;
+        v.K = k.K; v.TX = k.TX; v.TY = k.TY; v.NT = k.NT;
+        v.fn = launch_module;
+        v.kind = k.kind;
+        const bool ok_shape = k.kind == MK_POINTWISE ||
+                              (k.kind == MK_TICK && k.NT >= 64 && k.NT <= 1024 && k.K >= 1 && k.TX >= 1 && k.TY >= 1) ||
+                              (k.kind == MK_STRIP && k.NT < 0 && k.NT > -32 && k.K >= 2 && k.TX + 2 * (k.K - 1) <= 62 &&
+                               (k.TY + 2 * (k.K - 1) + (-k.NT) - 1) / (-k.NT) <= 16);
+        if (!k.symbol || !ok_shape || hipModuleGetFunction(&v.kern, m->mod, k.symbol) != hipSuccess) {
+            hipModuleUnload(m->mod);
+            delete m;
+            return fail(FIBHIP_EINVAL, "module_load: kernel %d (%s) is missing from the code object or has an impossible shape", i,
+                        k.symbol ? k.symbol : "(null)");
+        }
+        m->variants.push_back(v);
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int fibhip_module_unload(fibhip_module_t m)
+{
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    if (m->mod) hipModuleUnload(m->mod);
+    delete m;
     return 0;
 }
 

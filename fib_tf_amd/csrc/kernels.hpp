@@ -21,9 +21,6 @@
 //   threads, so consecutive lanes touch consecutive LDS words for all nine taps (conflict-free for
 //   any tile shape) and every lane of every wave has work.
 #pragma once
-#ifndef __HIPCC_RTC__
-#include <type_traits>
-#endif
 #include "models.hpp"
 
 namespace fib {
@@ -115,7 +112,7 @@ static FIB_DEV float phase_term(float N, float S, float Wv, float E, float dpy, 
 template <class P>
 static FIB_DEV float lap9(float N, float S, float Wv, float E, float NW, float SW, float NE, float SE, float C)
 {
-    if constexpr (std::is_same<P, Fast>::value) {
+    if constexpr (same_type<P, Fast>::value) {
         const float l1 = ((N + S) + Wv) + E, d = ((NW + SW) + NE) + SE;
         return __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
     } else {
@@ -125,7 +122,7 @@ static FIB_DEV float lap9(float N, float S, float Wv, float E, float NW, float S
 template <class P>
 static FIB_DEV float add_phase(float lap, float N, float S, float Wv, float E, float dpy, float dpx, float q4, float r4)
 {
-    if constexpr (std::is_same<P, Fast>::value)
+    if constexpr (same_type<P, Fast>::value)
         return __builtin_fmaf(__builtin_fmaf(E - Wv, dpx, (S - N) * dpy), r4, lap);
     else
         return lap + phase_term<P>(N, S, Wv, E, dpy, dpx, q4, r4);
@@ -147,7 +144,7 @@ struct ZeroPadOf {
     static constexpr bool value = false;
 };
 template <class M>
-struct ZeroPadOf<M, std::void_t<decltype(M::ZEROPAD)>> {
+struct ZeroPadOf<M, void_of<decltype(M::ZEROPAD)>> {
     static constexpr bool value = M::ZEROPAD;
 };
 
@@ -159,7 +156,7 @@ struct TwoPass {
     static constexpr int second(int mode) { return mode; }
 };
 template <class M>
-struct TwoPass<M, std::void_t<decltype(M::MODE_FASTSLOW)>> {
+struct TwoPass<M, void_of<decltype(M::MODE_FASTSLOW)>> {
     static constexpr bool of(int mode) { return mode == M::MODE_FASTSLOW; }
     static constexpr int first(int mode) { return mode == M::MODE_FASTSLOW ? M::MODE_FAST : mode; }
     static constexpr int second(int mode) { return mode == M::MODE_FASTSLOW ? M::MODE_SLOW : mode; }
@@ -271,7 +268,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                 float l = ZP ? stencil9_conv(N, S, Wv, E, NW, SW, NE, SE, C) : lap9<P>(N, S, Wv, E, NW, SW, NE, SE, C);
                 if (PHI_TILE) {     // same arithmetic as phase_prep_kernel + add_phase (IEEE division = Exact::divc)
                     const float dy = lphi[i + LP] - lphi[i - LP], dx = lphi[i + 1] - lphi[i - 1];
-                    if constexpr (std::is_same<P, Fast>::value) {
+                    if constexpr (same_type<P, Fast>::value) {
                         const float q4 = 4.0f * lphi[i];
                         l = add_phase<P>(l, N, S, Wv, E, dy, dx, q4, 1.0f / q4);           // r4 exactly as phase_prep_kernel forms it
                     } else {
@@ -596,7 +593,7 @@ static FIB_DEV float stencil9_lanes(float N, float S, float C, float dpy, float 
     const float Wv = lane_west(C), E = lane_east(C);
     const float l1 = (ns + Wv) + E, d = (lane_west(ns) + lane_east(N)) + lane_east(S);
     float r;
-    if constexpr (std::is_same<P, Fast>::value)
+    if constexpr (same_type<P, Fast>::value)
         r = __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
     else
         r = (l1 + 0.5f * d) - 6.0f * C;

@@ -20,12 +20,16 @@
 #pragma once
 #ifndef __HIPCC_RTC__            // hiprtc (in-process builds of traced models) brings its own runtime declarations
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #endif
 
 namespace fib {
 
 #define FIB_DEV __device__ __forceinline__
+
+// the two type traits the kernels need, spelled out: hiprtc has no <type_traits>
+template <class A, class B> struct same_type { static constexpr bool value = false; };
+template <class A> struct same_type<A, A> { static constexpr bool value = true; };
+template <class...> using void_of = void;
 
 // ---- R-wide value type --------------------------------------------------------------------------
 // The SIMD issues a wave's next VALU instruction at full rate only if it does not depend on the one

@@ -783,7 +783,7 @@ class IonicModel(_HostModel):
         if self._stepper is not None and self._compiled is not None:
             return
         c = self._analyze()
-        self._library = _build(c['source'])
+        self._library = _build(c['source'], device=self.device)
         for v in c['slots']:
             v._owner = self
         for v in c['host_vars']:
@@ -958,10 +958,83 @@ def _source_hash(src):
     return h.hexdigest()[:16]
 
 
-def _build(src, verbose=False):
-    """generated header -> _traced/libfibhip_<hash>.so (cached on the hash of the header and of csrc/)"""
+def _header_facts(src):
+    """what the host needs to know about a generated header: sizes, assign masks, plan hints (parsed from its text)"""
+    def num(pat):
+        return int(re.search(pat, src).group(1), 0)
+    facts = {'nvar': num(r'NVAR = (\d+);'), 'spt': num(r'DEFAULT_STEPS = (\d+);'), 'nmodes': num(r'NMODES = (\d+);'),
+             'consts_bytes': 4,
+             'plan': {k: num(r'#define FIB_CUSTOM_%s (\d+)' % k) for k in ('K', 'TX', 'TY', 'R', 'TYB', 'K2', 'TX2', 'TY2', 'R2')}}
+    masks = [0] * 8
+    for m in re.finditer(r'if \(mode == (\d+)\) return (0x[0-9A-Fa-f]+)u;', src):
+        masks[int(m.group(1))] = int(m.group(2), 16)
+    facts['masks'] = masks
+    return facts
+
+
+def _module_kernels(facts):
+    """the kernels a traced model needs, as csrc/fibhip.hip lists them for a per-model build: (name expression, meta)"""
+    p = facts['plan']
+    out = []
+    for fast, pol in ((0, 'fib::Exact'), (1, 'fib::Fast')):
+        for phase in (0, 1):
+            ph = 'true' if phase else 'false'
+            shapes = [(0, 1, 64, 4, 256)]                                    # kind, K, TX, TY, NT
+            if p['K'] > 1:
+                shapes.append((1, p['K'], p['TX'], p['TY'], -p['R']))
+                if p['TYB'] > 0:
+                    shapes.append((1, p['K'], p['TX'], p['TYB'], -p['R']))
+            if p['K2'] > 1 and p['K2'] != p['K']:
+                shapes.append((1, p['K2'], p['TX2'], p['TY2'], -p['R2']))
+            for kind, K, TX, TY, NT in shapes:
+                fn = 'tick_kernel' if kind == 0 else 'strip_kernel'
+                expr = 'fib::%s<fib::Custom, %s, 0, %d, %d, %d, %d, %s>' % (fn, pol, K, TX, TY, NT if kind == 0 else -NT, ph)
+                out.append((expr, {'kind': kind, 'mode': 0, 'fast': fast, 'phase': phase, 'K': K, 'TX': TX, 'TY': TY, 'NT': NT}))
+        for mode in range(1, facts['nmodes']):
+            expr = 'fib::pointwise_kernel<fib::Custom, %s, %d>' % (pol, mode)
+            out.append((expr, {'kind': 2, 'mode': mode, 'fast': fast, 'phase': 0, 'K': 1, 'TX': 0, 'TY': 0, 'NT': 0}))
+    return out
+
+
+_modules = {}
+
+
+def _build(src, verbose=False, device=None):
+    """generated header -> something `_lib.Stepper(library=...)` can run the model on.
+
+    Default: compiled IN THIS PROCESS by hiprtc into a code object (cached as _traced/model_<hash>.hsaco + .json on the
+    hash of the header and of csrc/) and loaded into the stock library (`fibhip_module_load`): no compiler on the box,
+    no library per model.  FIBTF_TRACED_BUILD=hipcc (or a runtime without libhiprtc): the translation unit built by
+    hipcc into _traced/libfibhip_<hash>.so, as before.  device=None compiles and caches only (no GPU needed)."""
     os.makedirs(CACHE, exist_ok=True)
     tag = _source_hash(src)
+    how = os.environ.get('FIBTF_TRACED_BUILD', 'hiprtc')
+    if how == 'hiprtc' and _lib.hiprtc() is not None:
+        hsaco = os.path.join(CACHE, 'model_%s.hsaco' % tag)
+        meta_path = os.path.join(CACHE, 'model_%s.json' % tag)
+        if not (os.path.exists(hsaco) and os.path.exists(meta_path)):
+            facts = _header_facts(src)
+            kernels = _module_kernels(facts)
+            code, lowered = _lib.rtc_compile('#include "kernels.hpp"\n', {'fib_custom_model.inc': src}, [e for e, _ in kernels],
+                                             _lib.RTC_OPTIONS + ['-DFIB_CUSTOM_MODEL_INC="fib_custom_model.inc"'])
+            facts['kernels'] = [dict(m, symbol=lowered[e]) for e, m in kernels]
+            for path, data, mode in ((hsaco, code, 'wb'), (meta_path, json.dumps(facts), 'w')):
+                tmp = '%s.%d.tmp' % (path, os.getpid())                 # atomic: several ranks may build the same model
+                with open(tmp, mode) as f:
+                    f.write(data)
+                os.replace(tmp, path)
+            if verbose:
+                print('hiprtc: %d kernels, %d bytes -> %s' % (len(kernels), len(code), os.path.relpath(hsaco)))
+        if device is None:
+            return None
+        key = (tag, device)
+        if key not in _modules:
+            with open(hsaco, 'rb') as f:
+                code = f.read()
+            with open(meta_path) as f:
+                meta = json.load(f)
+            _modules[key] = _lib.ModuleLibrary(code, meta, device, os.path.basename(hsaco))
+        return _modules[key]
     inc = os.path.join(CACHE, 'model_%s.inc' % tag)
     so = os.path.join(CACHE, 'libfibhip_%s.so' % tag)
     if not os.path.exists(so):
@@ -970,4 +1043,4 @@ def _build(src, verbose=False):
             f.write(src)
         os.replace(tmp, inc)
         _lib.build_custom(inc, so, verbose=verbose)
-    return _lib.load(so)
+    return None if device is None else _lib.load(so)

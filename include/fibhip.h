@@ -89,6 +89,8 @@ typedef struct fibhip_desc {
     void *stream;        /* hipStream_t to enqueue on (e.g. the caller's torch stream); NULL = own stream */
     void *ext_slab[2];   /* optional caller-owned DEVICE slabs, each nvar*height*width floats             */
                          /* (so that the caller can hand them to RCCL); NULL = library allocates          */
+    void *module;        /* model == FIBHIP_CUSTOM on the stock library: a fibhip_module_t (fibhip_module_load)  */
+                         /* holding the traced model's kernels; NULL otherwise                            */
 } fibhip_desc;
 
 /* model facts, usable before create: number of state arrays / default steps per tick */
@@ -203,6 +205,32 @@ int fibhip_comm_check(fibhip_t h, int rank, int nranks);   /* the local (non-col
 int fibhip_comm_init(fibhip_t h, const char *id128, int rank, int nranks);
 int fibhip_comm_exchange(fibhip_t h, int up_rank, int down_rank);
 int fibhip_comm_free(fibhip_t h);
+
+/* Run-time modules: a traced model (FIBHIP_CUSTOM) without a compiler on the box and without a library of its own.
+ * The caller compiles the model's DEVICE code in-process (hiprtc: the generated `struct Custom` + csrc/kernels.hpp,
+ * one name expression per kernel below) and hands the code object over; the stock library loads it and drives its
+ * kernels with the same host logic as the built-in models.  `fibhip_desc.module` then selects it at fibhip_create.  */
+typedef struct fibhip_module_kernel {
+    const char *symbol;  /* lowered (mangled) name of the kernel in the code object                           */
+    int kind;            /* 0 tick_kernel<Custom,P,MODE,K,TX,TY,NT,PHASE>, 1 strip_kernel<...,K,TX,TY,R,PHASE>,  */
+                         /* 2 pointwise_kernel<Custom,P,MODE> (an assign group fired by fibhip_step_mode)       */
+    int mode, fast, phase;
+    int K, TX, TY, NT;   /* NT: threads per workgroup (tick) or -R (strip), as csrc/fibhip.hip lists its own    */
+} fibhip_module_kernel;
+typedef struct fibhip_module_desc {
+    int struct_size;     /* sizeof(fibhip_module_desc)                                                        */
+    int nvar;            /* Custom::NVAR                                                                      */
+    int steps_per_tick;  /* Custom::DEFAULT_STEPS                                                             */
+    int nmodes;          /* Custom::NMODES (assign groups; mode 0 = the tick op)                              */
+    unsigned masks[8];   /* Custom::mask(mode): which arrays each group assigns                               */
+    int consts_bytes;    /* sizeof(Custom::Consts)                                                            */
+    int K, TX, TY, R, TYB, K2, TX2, TY2, R2;   /* FIB_CUSTOM_* plan hints of the generated header              */
+    int nkernels;
+    const fibhip_module_kernel *kernels;
+} fibhip_module_desc;
+typedef struct fibhip_module *fibhip_module_t;
+int fibhip_module_load(int device, const void *code, size_t nbytes, const fibhip_module_desc *d, fibhip_module_t *out);
+int fibhip_module_unload(fibhip_module_t m);   /* after every handle created on it has been destroyed */
 
 /* measurement aid: best-of-`reps` rate of a plain device-to-device streaming copy of nbytes (read + written bytes
  * per second, GB/s) — the achievable-bandwidth yardstick printed next to the roofline peak                  */

@@ -49,7 +49,8 @@ def test_traced_model_matches_graph_interpreter(gpu_lib, name, H, W, hole, ticks
         assert np.allclose(trend, wtrend, rtol=0, atol=tol * 130)
     # the library that ran is the one generated for this model, and the whole tick is one fused launch
     import ctypes
-    assert 'libfibhip_' in m._library._name and '_traced' in m._library._name
+    # ... compiled in this process (hiprtc) and loaded into the stock library as a run-time module
+    assert '#module:model_' in m._library._name and m._library.module.value
     fused, launches = m._stepper.launch_plan()
     assert (fused, launches) == (m.dt_per_step, 1)
     assert m.generated_source().count('struct Custom') == 1
@@ -163,6 +164,24 @@ def test_generated_eight_variable_vs_handwritten(gpu_lib, golden):
         for i, n in enumerate(names):
             _close(got[i], f['%s_t%d' % (n, t)], 3e-5, 'ev %s t%d' % (n, t), scales.get(n, 1.0))
             _close(got[i], hand[i], 3e-5, 'ev vs hand-written %s t%d' % (n, t), scales.get(n, 1.0))
+
+
+@pytest.mark.parametrize('name,ticks', [('ap', 12), ('gated', 35), ('fvc', 20)])
+def test_inprocess_build_equals_compiler_build(gpu_lib, name, ticks, monkeypatch):
+    """the two ways a traced model reaches the GPU — hiprtc in this process -> code object -> fibhip_module_load into
+    the stock library (default), and hipcc -> a per-model build of libfibhip (FIBTF_TRACED_BUILD=hipcc) — run the same
+    generated source through the same kernels: bitwise equal states, incl. the 'slow' assign group of `gated`
+    (pointwise_kernel through the module API) and the ZEROPAD variant"""
+    res = []
+    for how in ('hiprtc', 'hipcc'):
+        monkeypatch.setenv('FIBTF_TRACED_BUILD', how)
+        m = make_model(name, 60, 72, (30, 30, 7) if name != 'fvc' else None)
+        m.define()
+        st, trend = drive(m, name, ticks, 5)
+        assert ('#module:' in m._library._name) == (how == 'hiprtc')
+        res.append((st, trend, m._stepper.launch_plan()))
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize('name', ['ap', 'mrfhn'])
