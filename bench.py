@@ -304,6 +304,7 @@ def measure_single(args, exact, with_extras):
     snaps = None
     if with_extras:
         roofline_extras(roof, kernel_key(args, exact, m.height, m.width, fused), us_per_launch)
+        m.image()                                     # set-up: the pinned staging buffer of the read-backs
         ws = timed_regions(advance, st.sync, args.steps, 1, snap=True)
         snaps = cells * args.steps * spt / ws[0] / 1e6
     return value, wall * 1000.0 / args.steps, roof, walls, snaps, m
