@@ -119,13 +119,44 @@ template <class F> FIB_DEV float vzip(float a, float b, F f) { return f(a, b); }
 // IEEE division at 3 instructions instead of the ~11 of the generic expansion.  Checked exhaustively
 // over all 2^23 significands for every constant of the three models (tools/ubench/divtest.c);
 // it can differ only when a/c is subnormal (by at most one subnormal ulp).
+// exp and expm1 for the rounding-faithful policy, branch-free.
+//   exp:   v_exp_f32 on x*log2(e) and ONE correction step for the rounding of that product (log2(e) in two terms):
+//          7 instructions against ocml's 18; <= 1 ulp + the instruction's own error (measured on the device,
+//          tools/ubench/acc_rf.hip).  Results below 2^-126 flush to zero.
+//   expm1: no transcendental instruction at all: x = n ln2 + r, expm1(x) = 2^n expm1(r) + (2^n - 1) with the degree-7
+//          Taylor form on |r| <= 0.35; 17 instructions against ocml's 31, <= 0.9 ulp for x < 0 — the only sign a positive
+//          time constant gives rush_larsen — and <= 1.7 ulp for x > 0.
+static FIB_DEV float exp_core(float x)                              // x <= 88.72 (e must stay finite)
+{
+    constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.92596299112661746e-8f, LN2 = 0.693147180559945f;
+    const float t = x * L2E_HI;
+    const float lo = __builtin_fmaf(x, L2E_LO, __builtin_fmaf(x, L2E_HI, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, lo * LN2, e);
+}
+static FIB_DEV float exp_rf(float x) { return exp_core(__builtin_fminf(x, 88.72f)); }   // exp(88.72) is the last finite value
+static FIB_DEV float expm1_rf(float x)
+{
+    constexpr float L2E = 1.44269504088896340736f, LN2_HI = 0.693147180559945f, LN2_LO = -1.90465429995776804525e-9f;
+    x = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 88.0f);         // 2^n stays finite (and -inf stays out of n*ln2)
+    const float n = __builtin_rintf(x * L2E);
+    const float r = __builtin_fmaf(n, -LN2_LO, __builtin_fmaf(n, -LN2_HI, x));
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    const float q = __builtin_fmaf(p * r, r, r);
+    const float s = __builtin_ldexpf(1.0f, (int)n);
+    return __builtin_fmaf(s, q, s - 1.0f);
+}
 // tanh for the rounding-faithful policy: branch-free, <= 1.4 ulp of the true tanh over the whole float32 range
 // (tools/ubench/tanh_test.c: 32 M samples; glibc's tanhf: 2.2 ulp, the float32 tanh TensorFlow's CPU kernels use is a
-// rational approximation of a few ulp too) at ~27 instructions and two transcendental issues, where ocml's tanhf
+// rational approximation of a few ulp too) at ~23 instructions and two transcendental issues, where ocml's tanhf
 // runs both of its divergent branches at ~4x that.
 //   |x| < 0.625:  x + x*z*P(z), z = x^2              (Cephes tanhf's polynomial)
-//   otherwise:    1 - 2/(e + 1), e = exp(2|x|) = 2^f * 2^n with log2(e) split in two terms and f in [-1/2, 1/2] on
-//                 v_exp_f32, the quotient by v_rcp_f32 + one Newton step
+//   otherwise:    1 - 2/(e + 1), e = exp(2|x|) by exp_core above, the quotient by v_rcp_f32 + one Newton step
 static FIB_DEV float tanh_rf(float x)
 {
     const float a = __builtin_fabsf(x);
@@ -136,43 +167,14 @@ static FIB_DEV float tanh_rf(float x)
     p = __builtin_fmaf(p, z, 1.33314422036e-1f);
     p = __builtin_fmaf(p, z, -3.33332819422e-1f);
     const float small = __builtin_fmaf(p * z, a, a);
-    const float y = 2.0f * __builtin_fminf(a, 10.0f);                 // tanh(10) rounds to 1; keeps 2^n finite
-    constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.92596299112661746e-8f;
-    const float t = y * L2E_HI;
-    const float n = __builtin_rintf(t);
-    const float f = (__builtin_fmaf(y, L2E_HI, -t) + y * L2E_LO) + (t - n);
-    const float e = __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+    const float y = 2.0f * __builtin_fminf(a, 10.0f);                 // tanh(10) rounds to 1; keeps e finite
+    const float e = exp_core(y);
     const float d = e + 1.0f;
     float r = __builtin_amdgcn_rcpf(d);
     r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
     const float big = __builtin_fmaf(-2.0f, r, 1.0f);
     const float res = !(a >= 0.625f) ? small : big;                  // (a NaN takes the polynomial and stays a NaN)
     return __builtin_copysignf(res, x);
-}
-
-// exp and expm1 for the rounding-faithful policy, branch-free (tools/ubench/expm1_test.c, 50 M samples per sign):
-// exp <= 0.65 ulp (1.6 in the subnormal range), expm1 <= 1.25 ulp for x < 0 — the only sign a positive time constant
-// gives rush_larsen — and <= 2.5 ulp for x > 0; 12 and 22 instructions against ocml's 18 and 31.
-static FIB_DEV float exp_rf(float x)
-{
-    constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.92596299112661746e-8f;
-    x = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);        // 2^n stays finite; exp(89) is +inf already
-    const float t = x * L2E_HI;
-    const float n = __builtin_rintf(t);
-    const float f = (__builtin_fmaf(x, L2E_HI, -t) + x * L2E_LO) + (t - n);
-    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
-}
-static FIB_DEV float expm1_rf(float x)
-{
-    float p = 1.0f / 5040.0f;                                       // |x| < 0.35: Taylor to x^7 (truncation 2e-8)
-    p = __builtin_fmaf(p, x, 1.0f / 720.0f);
-    p = __builtin_fmaf(p, x, 1.0f / 120.0f);
-    p = __builtin_fmaf(p, x, 1.0f / 24.0f);
-    p = __builtin_fmaf(p, x, 1.0f / 6.0f);
-    p = __builtin_fmaf(p, x, 0.5f);
-    const float small = __builtin_fmaf(p * x, x, x);
-    const float big = exp_rf(x) - 1.0f;
-    return !(__builtin_fabsf(x) >= 0.35f) ? small : big;
 }
 
 struct Exact {
