@@ -46,7 +46,7 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 // kernel variants
 // ------------------------------------------------------------------------------------------
-constexpr int FIB_MAXVAR = 22;   // CourtemancheUS
+constexpr int FIB_MAXVAR = 26;   // CourtAgg: 21 state arrays + 5 aggregates (CourtemancheUS: 22)
 
 struct LaunchCtx {
     Geo g;
@@ -184,6 +184,7 @@ static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
 }
 
 constexpr int VM_FENTON_ZP = 100;   // variant-table id of FentonZP (not a fibhip_model: selected by FIBHIP_ZEROPAD)
+constexpr int VM_COURT_AGG = 101;   // variant-table id of CourtAgg (Courtemanche, fast policy, one device: fibhip_ctx::use_agg)
 
 struct Variant {
     int model, mode, fast, phase;
@@ -196,6 +197,11 @@ struct Variant {
 #define V4(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
     {MID, MODE, 0, 0, K, TX, TY, NT, launch_tick<MODEL, Exact, MODE, K, TX, TY, NT, false>},       \
     {MID, MODE, 0, 1, K, TX, TY, NT, launch_tick<MODEL, Exact, MODE, K, TX, TY, NT, true>},        \
+    {MID, MODE, 1, 0, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, false>},        \
+    {MID, MODE, 1, 1, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, true>}
+
+// fast-policy-only models (CourtAgg)
+#define F2(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
     {MID, MODE, 1, 0, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, false>},        \
     {MID, MODE, 1, 1, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, true>}
 
@@ -304,6 +310,10 @@ static const Variant g_variants[] = {
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FAST, 1, 64, 8, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_ALL, 1, 64, 4, 256),
     V4(Courtemanche, FIBHIP_COURT, Courtemanche::MODE_FASTSLOW, 1, 64, 4, 256),
+    // the fast tick on the five per-cell aggregates of the slow variables (models.hpp CourtAgg)
+    F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 1, 64, 4, 256),
+    F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 1, 64, 8, 256),
+    F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FASTSLOW, 1, 64, 4, 256),
     // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
     V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
 #endif
@@ -368,6 +378,11 @@ struct fibhip_ctx {
     void *comm;             // ncclComm_t of the direct halo path (fibhip_comm_*), or null
     float *probe_host;      // pinned
     float *stage;           // pinned staging buffer for get_state/set_state (one array), allocated on first use
+    // Courtemanche, fast policy, one device, planar state: the fast tick reads five per-cell aggregates of the slow
+    // variables (models.hpp CourtAgg) instead of the variables themselves.  'slow' rewrites them; any other write to the
+    // state (set_state) marks them stale and the next tick recomputes them first.
+    float *agg;             // CourtAgg::NAGG arrays of `cells` floats, or null
+    bool use_agg, agg_dirty;
 };
 
 static const void *consts_of(fibhip_ctx *h)
@@ -425,7 +440,8 @@ static const Variant *find_variant(const fibhip_ctx *h, int K, const int *want /
     const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
     if (mode < 0) mode = h->mode;
     // fenton_simple.py's Laplacian is a property of the kernel's model type (FentonZP): its own rows of the table
-    const int vmodel = (h->d.model == FIBHIP_FENTON4V && (h->d.flags & FIBHIP_ZEROPAD)) ? VM_FENTON_ZP : h->d.model;
+    const int vmodel = (h->d.model == FIBHIP_FENTON4V && (h->d.flags & FIBHIP_ZEROPAD)) ? VM_FENTON_ZP
+                       : (h->use_agg ? VM_COURT_AGG : h->d.model);
     const Variant *tab = h->mod ? h->mod->variants.data() : g_variants;
     const int ntab = h->mod ? (int)h->mod->variants.size() : g_nvariants;
     for (int i = 0; i < ntab; ++i) {
@@ -727,6 +743,19 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->fused_fn = nullptr;
     h->comm = nullptr;
     h->tuned = false;
+    h->agg = nullptr;
+    h->use_agg = false;
+    h->agg_dirty = true;
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    {
+        const char *e = getenv("FIBHIP_COURT_AGG");
+        if (desc->model == FIBHIP_COURT && (desc->flags & FIBHIP_FAST) && !(desc->flags & FIBHIP_ALLVARS) &&
+            !desc->ghost_top && !desc->ghost_bottom && h->pitch == desc->width && h->own_slab && !(e && atoi(e) == 0)) {
+            HIPCHK(hipMalloc((void **)&h->agg, (size_t)CourtAgg::NAGG * h->cells * sizeof(float)));
+            h->use_agg = true;
+        }
+    }
+#endif
     return build_plan(h);
 }
 
@@ -745,6 +774,7 @@ extern "C" int fibhip_destroy(fibhip_t h)
     }
     if (h->phase3) hipFree(h->phase3);
     if (h->phi_dev) hipFree(h->phi_dev);
+    if (h->agg) hipFree(h->agg);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->stage) hipHostFree(h->stage);
     if (h->ev_main) hipEventDestroy(h->ev_main);
@@ -825,6 +855,7 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
     // does not: mid-cycle the other arrays' outer ghost rows are stale, so the cycle position stays and the rows
     // of `var` that are still live at this position are the ones the caller's copy has to be right in.
     if (var < 0) h->cpos = 0;
+    h->agg_dirty = true;
     return 0;
 }
 
@@ -875,13 +906,23 @@ static unsigned tick_mask(const fibhip_ctx *h)
     switch (h->d.model) {
     case FIBHIP_FENTON4V: return Fenton::mask(h->mode);
     case FIBHIP_BR: return BeelerReuter::mask(h->mode);
-    case FIBHIP_COURT: return Courtemanche::mask(h->mode);
+    case FIBHIP_COURT: return h->use_agg ? CourtAgg::mask(h->mode) : Courtemanche::mask(h->mode);
     case FIBHIP_COURT_US: return CourtemancheUS::mask(h->mode);
 #ifdef FIB_CUSTOM_MODEL_INC
     case FIBHIP_CUSTOM: return Custom::mask(h->mode);
 #endif
     default: return ~0u;
     }
+}
+
+// the aggregate arrays follow the state arrays in the pointer table of the CourtAgg kernels (read and written in place)
+static void agg_ptrs(const fibhip_ctx *h, LaunchCtx &c)
+{
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    if (!h->use_agg) return;
+    for (int a = 0; a < CourtAgg::NAGG; ++a)
+        c.in[Courtemanche::NVAR + a] = c.out[Courtemanche::NVAR + a] = h->agg + (size_t)a * h->cells;
+#endif
 }
 
 static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *nxt)
@@ -895,6 +936,7 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
         c.in[v] = h->slab[cur[v]] + (size_t)v * h->vstride;
         c.out[v] = h->slab[nxt[v]] + (size_t)v * h->vstride;
     }
+    agg_ptrs(h, c);
     c.ph.dpy = h->phase3;
     c.ph.dpx = h->phase3 + h->cells;
     c.ph.q4 = h->phase3 + 2 * h->cells;
@@ -1043,12 +1085,27 @@ static int autotune(fibhip_ctx *h)
     return 0;
 }
 
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr);
+
+// Courtemanche on aggregates: recompute them if the state was written from outside since they were formed
+static int refresh_agg(fibhip_t h)
+{
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    if (h->use_agg && h->agg_dirty) {
+        if (int rc = run_pointwise_mode(h, launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_AGG>, nullptr)) return rc;
+        h->agg_dirty = false;
+    }
+#endif
+    return 0;
+}
+
 static int edges_impl(fibhip_t h)
 {
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step_edges: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
     if (!h->tuned)
         if (int rc = autotune(h)) return rc;
+    if (int rc = refresh_agg(h)) return rc;
     int cur[FIB_MAXVAR];
     memcpy(cur, h->cur, sizeof cur);
     int sub = 0;
@@ -1187,7 +1244,7 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
 }
 
 // re-evaluation of the model on the current state, in place, without the stencil: assigns mask(mode)
-static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr)
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv)
 {
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_mode inside an open tick");
     LaunchCtx c;
@@ -1202,6 +1259,7 @@ static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = null
         c.in[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;
         c.out[v] = h->slab[h->cur[v]] + (size_t)v * h->vstride;   // in place
     }
+    agg_ptrs(h, c);
     c.consts = consts_of(h);
     c.g = base_geo(h);
     // the ghost rows that later ticks of this cycle still advance must get the update too
@@ -1259,6 +1317,10 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
             return rc;
         }
         FLUSH(h);
+        if (h->use_agg) {                                 // 'slow' on the state as it stands; the aggregates follow it
+            h->agg_dirty = false;
+            return run_pointwise_mode(h, launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_SLOW>);
+        }
         return run_pointwise_mode(h, fast ? launch_pointwise<Courtemanche, Fast, Courtemanche::MODE_SLOW>
                                           : launch_pointwise<Courtemanche, Exact, Courtemanche::MODE_SLOW>);
     }
@@ -1683,6 +1745,10 @@ extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
     FLUSH(h);
+    if (h->use_agg) {                   // the caller may write through the pointer at any time: back to the plain kernels
+        h->use_agg = false;
+        if (int rc = build_plan(h)) return rc;
+    }
     *dev_ptr = h->slab[h->cur[var]] + (size_t)var * h->vstride;
     return h->cur[var];
 }

@@ -542,6 +542,130 @@ struct CourtT {
 using Courtemanche = CourtT<false>;
 using CourtemancheUS = CourtT<true>;
 
+// -------------------------------------------------------------------------------------------------------------------
+// Courtemanche under the fast policy on one device: the fast tick with the slow variables folded.
+// court.py:94-103 assigns V, Na_i, m, h on every tick and the other 17 variables only when the driver fires 'slow'
+// (every 10th tick, court.py:612-617).  Between two 'slow' ops the fast tick needs those 17 only through
+//     S1   = c_to oa^3 oi + Cm g_Ks xs^2          (times V - E_K: i_to + i_Ks,            court.py:193,197)
+//     PKur = c_Kur ua^3 ui                         (times g_Kur(V) (V - E_K): i_Kur,       court.py:194)
+//     EK   = RT/F log(K_o / K_i)                                                            (court.py:191)
+//     PCaL = c_CaL d f f_Ca                        (times V - 65: i_Ca_L,                  court.py:218)
+//     C0   = i_CaP - Cm g_B_Ca E_Ca                (Ca_i is a slow variable,               court.py:219-221)
+// and j, xr, Ca_i themselves.  'slow' (and any write to the state from outside) refreshes the five arrays; the fast
+// tick then reads 12 arrays instead of 16 and drops two logarithms, four divisions and the cubes.  The sums are
+// re-associated and fused (FMA), equal exponentials are formed once, 1/tau is never inverted twice: a few ulp per
+// current, like everything under the fast policy — the rounding-faithful policy never takes this path.
+// Arrays 21..25 of the kernels' pointer table are the five aggregates (fibhip.hip: fibhip_ctx::agg).
+struct CourtAgg : CourtT<false> {
+    typedef CourtT<false> Base;
+    static constexpr int NAGG = 5;
+    static constexpr int NVAR = Base::NVAR + NAGG;
+    enum { a_S1 = Base::NVAR, a_PKur, a_EK, a_PCaL, a_C0 };
+    enum { MODE_AGG = 4 };                        // only the aggregates, from the state as it stands
+    static constexpr unsigned AGG_MASK = ((1u << NAGG) - 1u) << Base::NVAR;
+    static constexpr unsigned mask(int mode)
+    {
+        return mode == MODE_FAST ? FAST_MASK : (mode == MODE_AGG ? AGG_MASK : (Base::mask(mode) | AGG_MASK));
+    }
+    static FIB_DEV float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+    static FIB_DEV float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+    static FIB_DEV float fm(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+    static FIB_DEV void aggregates(float (&s)[NVAR], const Consts &k)
+    {
+        constexpr double R = 8.3143, T = 310, Fd = 96.4867, Cm = 100, K_o = 5.4, g_Ks = 0.12941176, Ca_o = 1.8;
+        constexpr double i_CaP_max = 0.275, g_B_Ca = 0.001131;
+        constexpr float RTF = FC((R * T) / Fd), RT2F = FC((R * T) / (2.0 * Fd));
+        s[a_S1] = fm(FC(Cm * g_Ks) * s[i_xs], s[i_xs], ((k.c_to * pow3(s[i_oa])) * s[i_oi]));
+        s[a_PKur] = (k.c_Kur * pow3(s[i_ua])) * s[i_ui];
+        s[a_EK] = RTF * Fast::log(Fast::div(FC(K_o), s[iK_i]));
+        s[a_PCaL] = ((k.c_CaL * s[i_d]) * s[i_f]) * s[i_f_Ca];
+        const float Cai = s[iCa_i];
+        const float i_CaP = Fast::div(FC(Cm * i_CaP_max) * Cai, FC(0.0005) + Cai);
+        const float E_Ca = RT2F * Fast::log(Fast::div(FC(Ca_o), Cai));
+        s[a_C0] = fm(E_Ca, FC(-(Cm * g_B_Ca)), i_CaP);
+    }
+
+    // the fast set (V, Na_i, m, h) from the boundary-enforced potential, its Laplacian and the aggregates
+    static FIB_DEV void fast(float (&s)[NVAR], float V, float lap, const Consts &k)
+    {
+        constexpr double L2E = 1.44269504088896340736, LN2 = 0.69314718055994530942;
+        constexpr double R = 8.3143, T = 310, Fd = 96.4867, Cm = 100, g_Na = 7.8, Na_o = 140, K_o = 5.4;
+        constexpr double Km_K_o = 1.5, i_NaK_max = 0.59933874, g_B_Na = 0.0006744375, g_K1 = 0.09;
+        constexpr double g_Kr = 0.029411765, Ca_o = 1.8, I_NaCa_max = 1600, K_mNa = 87.5, K_mCa = 1.38, K_sat = 0.1;
+        constexpr double gamma_ = 0.35, V_cell = 20100, V_i = V_cell * 0.68;
+        constexpr double FRT = Fd / (R * T), RTF = (R * T) / Fd;
+        const float Nai = s[iNa_i], m = s[i_m], h = s[i_h], j = s[i_j], xr = s[i_xr], Cai = s[iCa_i];
+        const float eps = V * FC(1e-20);                                                           // court.py:298
+
+        // --- m (court.py:320-329) and h (:331-344): 1/tau = alpha + beta is used as it is
+        const float vq = V + FC(47.13);
+        const float n_m = FC(0.32) * vq, d_m = 1.0f - ex2(vq * FC(-0.1 * L2E));
+        const float al_m = (fabsf(vq) < FC(0.001)) ? eps + FC(3.2) : n_m * rcpf(d_m);
+        const float rate_m = fm(ex2(V * FC(-L2E / 11.0)), FC(0.08), al_m);
+        const float m_inf = al_m * rcpf(rate_m);
+        const float m1 = clipf(fm(m - m_inf, ex2(rate_m * (k.mdt_f * FC(L2E))) - 1.0f, m), 0.00001f, 0.99999f);
+
+        const bool lo = V < -40.0f;
+        // one exponential serves both branches: exp((V+80)/-6.8) below -40 mV, exp((V+10.66)/-11.1) above
+        const float e_a = ex2(fm(V, lo ? FC(L2E / -6.8) : FC(L2E / -11.1), lo ? FC(80.0 * L2E / -6.8) : FC(10.66 * L2E / -11.1)));
+        const float be_lo = fm(ex2(V * FC(0.35 * L2E)), 310000.0f, FC(3.56) * ex2(V * FC(0.079 * L2E)));
+        const float be_hi = rcpf(fm(e_a, FC(0.13), FC(0.13)));
+        const float al_h = lo ? FC(0.135) * e_a : eps;
+        const float rate_h = al_h + (lo ? be_lo : be_hi);
+        const float h_inf = al_h * rcpf(rate_h);
+        const float h1 = clipf(fm(h - h_inf, ex2(rate_h * (k.mdt_f * FC(L2E))) - 1.0f, h), 0.00001f, 0.99999f);
+
+        // --- sodium (court.py:206-215): E_Na and (K_m/Na_i)^1.5 from ONE logarithm
+        const float l2 = __builtin_amdgcn_logf(Nai);                                              // log2(Na_i)
+        const float vENa = V - fm(l2, FC(-RTF * LN2), FC(RTF * 4.9416424226093039));             // log(140) = 4.94164...
+        const float gNa = fm(((FC(Cm * g_Na) * pow3(m)) * h), j, FC(Cm * g_B_Na));               // i_Na + i_B_Na = gNa (V - E_Na)
+        const float i_Nas = gNa * vENa;
+        const float x = V * FC(FRT * L2E);                                                        // F V / (R T), base-2 scaled
+        const float e8 = ex2(x * -0.1f), e9 = ex2(-x);                                           // court.py:417
+        const float pw = ex2(fm(l2, -1.5f, FC(1.5 * 3.3219280948873623)));                        // (Km_Na_i / Na_i)^1.5, Km_Na_i = 10
+        const float i_NaK = FC(Cm * i_NaK_max * (K_o / (K_o + Km_K_o))) *
+                            rcpf(fm(e9, FC(0.0365), fm(e8, FC(0.1245), 1.0f)) * (1.0f + pw));    // :202,417
+        const float e10 = ex2(x * FC(gamma_ - 1.0)), e11 = ex2(x * FC(gamma_));                   // :419-423 (e10 twice there)
+        constexpr double cd = (K_mNa * K_mNa * K_mNa + Na_o * Na_o * Na_o) * (K_mCa + Ca_o);
+        const float i_NaCa = fm(FC(Cm * I_NaCa_max * Ca_o / cd) * e11, pow3(Nai), -(FC(Cm * I_NaCa_max * Na_o * Na_o * Na_o / cd) * e10) * Cai) *
+                             rcpf(fm(e10, FC(K_sat), 1.0f));                                      // :211
+
+        // --- potassium (court.py:191-204): everything times V - E_K
+        const float vEK = V - s[a_EK];
+        const float i_K1a = FC(Cm * g_K1) * rcpf(1.0f + ex2(fm(V, FC(0.07 * L2E), FC(0.07 * 80.0 * L2E))));          // :425
+        const float i_Kra = FC(Cm * g_Kr) * rcpf(1.0f + ex2(fm(V, FC(L2E / 22.4), FC(15.0 * L2E / 22.4))));          // :427
+        const float g_Kur = fm(rcpf(1.0f + ex2(fm(V, FC(L2E / -13.0), FC(-15.0 * L2E / -13.0)))), FC(0.05), FC(0.005));  // :415
+        const float X = fm(g_Kur, s[a_PKur], fm(i_Kra, xr, i_K1a + s[a_S1]));
+
+        // --- potential (court.py:217-229)
+        const float i_Cas = fm(s[a_PCaL], V - 65.0f, fm(V, FC(Cm * 0.001131), s[a_C0]));          // i_Ca_L + i_B_Ca + i_CaP
+        const float isum = fm(X, vEK, i_Nas) + ((i_NaK + i_NaCa) + i_Cas);
+        s[iV] = fm(lap, k.ddt, fm(isum, k.dtf * FC(-1.0 / Cm), V));
+        s[iNa_i] = fm(fm(3.0f, i_NaK + i_NaCa, i_Nas), k.dtf * FC(-1.0 / (V_i * Fd)), Nai);
+        s[i_m] = m1;
+        s[i_h] = h1;
+    }
+
+    template <class P, int MODE>
+    static FIB_DEV void step(float (&s)[NVAR], float V, float lap, const Consts &k, int sub)
+    {
+        if constexpr (MODE == MODE_FAST) {
+            fast(s, V, lap, k);
+        } else if constexpr (MODE == MODE_AGG) {
+            aggregates(s, k);
+        } else {                                   // MODE_SLOW (also the second pass of MODE_FASTSLOW)
+            float b[Base::NVAR];
+#pragma unroll
+            for (int v = 0; v < Base::NVAR; ++v) b[v] = s[v];
+            Base::template step<P, MODE>(b, V, lap, k, sub);
+#pragma unroll
+            for (int v = 0; v < Base::NVAR; ++v) s[v] = b[v];
+            aggregates(s, k);
+        }
+    }
+};
+
 // =====================================================================================
 // A model traced from a user's reference-style Python file (fib_tf_amd/traced.py) is emitted as
 // `struct Custom` into a generated header and compiled in here (FIBHIP_CUSTOM).

@@ -184,6 +184,101 @@ def test_court_fused_slow_tick_is_bit_identical(gpu_lib, policy, H, W, monkeypat
     assert np.array_equal(res[0][1], res[1][1])
 
 
+def _court_run(monkeypatch, agg, H, W, poke=None, ticks=57):
+    """raw C ABI: `ticks` fast ticks, 'slow' after every 10th, one S2-style pace, optionally a host write in between"""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.court import INITIAL
+    if agg:
+        monkeypatch.delenv('FIBHIP_COURT_AGG', raising=False)
+    else:
+        monkeypatch.setenv('FIBHIP_COURT_AGG', '0')
+    rng = np.random.default_rng(11)
+    init = np.empty((21, H, W), np.float32)
+    for i, (_, v) in enumerate(INITIAL):
+        init[i] = v
+    init[0] += rng.uniform(-5, 60, (H, W)).astype(np.float32)
+    phi = rng.uniform(0.3, 1.0, (H, W)).astype(np.float32)
+    st = _lib.Stepper(_lib.COURT, H, W, 0.1, 0.809, flags=_lib.FAST)
+    st.set_phase(phi)
+    st.set_state(-1, init)
+    snaps = []
+    for i in range(ticks):
+        st.step(1)
+        if i % 10 == 0:
+            st.step_slow()
+        if i == 12:
+            st.pace(0, max(1, H // 2), 0, max(1, W // 2), 10.0, -100.0)
+        if poke and i == poke[0]:
+            st.set_state(poke[1], poke[2])
+        if i in (0, 9, 10, 11, 30, ticks - 1):
+            snaps.append(st.get_state(-1))
+    st.close()
+    return snaps
+
+
+COURT_SCALES = [150.0, 1.0] + [1.0] * 3 + [1.0] + [1.0] * 6 + [1e-3] + [1.0] * 3 + [1.5] + [1.0] * 3 + [1.0]
+# the SR-release subsystem switches through a sigmoid one ulp of Fn wide (see test_court_trajectory): looser there
+COURT_CALCIUM = (12, 15, 16, 17, 18, 19, 20)
+
+
+def court_rel(v):
+    # V itself: 2e-5 * 150 mV = 3e-3 mV; a gate follows V with a slope of up to 0.05 per mV (oi_inf, court.py:371)
+    return 1e-3 if v in COURT_CALCIUM else (2e-5 if v in (0, 1, 5) else 2e-4)
+
+
+@pytest.mark.parametrize('H,W', [(70, 66), (65, 64), (40, 131)])
+def test_court_aggregated_fast_tick(gpu_lib, monkeypatch, H, W):
+    """Courtemanche, fast policy, one device: the tick kernels read five per-cell aggregates of the slow variables
+    (CourtAgg, models.hpp) that 'slow' maintains, instead of the 12 variables they are made of.  Against the plain
+    kernels (FIBHIP_COURT_AGG=0) on the same inputs the trajectories agree to the fast policy's own tolerance —
+    the sums are re-associated, nothing else changes — across 'slow' ops (fused and, on the 65-row grid, separate)"""
+    a = _court_run(monkeypatch, True, H, W)
+    b = _court_run(monkeypatch, False, H, W)
+    for sa, sb in zip(a, b):
+        for v in range(21):
+            assert_close(sa[v], sb[v], court_rel(v), 'var %d' % v, scale=COURT_SCALES[v])
+
+
+def test_court_aggregates_follow_host_writes(gpu_lib, monkeypatch):
+    """set_state of a slow variable between two ticks: the aggregates are recomputed before the next tick (a stale
+    aggregate would keep the old conductance: compare with the plain kernels after the write)"""
+    H, W = 48, 70
+    xs = np.full((H, W), 0.6, np.float32)                  # _xs_ (index 11): i_Ks = Cm g_Ks xs^2 (V - E_K)
+    d = np.full((H, W), 0.4, np.float32)                   # _d_ (index 13): i_Ca_L
+    for poke in ((15, 11, xs), (23, 13, d)):
+        a = _court_run(monkeypatch, True, H, W, poke=poke, ticks=31)
+        b = _court_run(monkeypatch, False, H, W, poke=poke, ticks=31)
+        assert float(np.abs(a[-1][0] - _court_run(monkeypatch, True, H, W, ticks=31)[-1][0]).max()) > 1e-3   # the write matters
+        for v in range(21):
+            assert_close(a[-1][v], b[-1][v], court_rel(v), 'var %d after a host write' % v, scale=COURT_SCALES[v])
+
+
+def test_court_aggregates_off_after_state_ptr(gpu_lib, monkeypatch):
+    """a raw device pointer handed out (fibhip_state_ptr) means the state can change behind the library's back: the
+    handle returns to the plain kernels and keeps producing the plain kernels' bits"""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.court import INITIAL
+    monkeypatch.delenv('FIBHIP_COURT_AGG', raising=False)
+    H, W = 40, 70
+    init = np.empty((21, H, W), np.float32)
+    for i, (_, v) in enumerate(INITIAL):
+        init[i] = v
+    out = []
+    for ptr in (True, False):
+        if not ptr:
+            monkeypatch.setenv('FIBHIP_COURT_AGG', '0')
+        st = _lib.Stepper(_lib.COURT, H, W, 0.1, 0.809, flags=_lib.FAST)
+        st.set_state(-1, init)
+        if ptr:
+            st.state_buf(5)
+        st.step(12)
+        st.step_slow()
+        st.step(3)
+        out.append(st.get_state(-1))
+        st.close()
+    assert np.array_equal(out[0], out[1])
+
+
 SINGULAR = [-10.0001, -10.0, 7.9, -47.13, -14.1, 3.3328, 19.9]
 
 
