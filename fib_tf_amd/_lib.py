@@ -98,6 +98,7 @@ SYMBOLS = {
     'fibhip_module_load': ([C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ModuleDesc), C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_module_unload': ([C.c_void_p], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
+    'fibhip_ticks_per_launch': ([_h], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
 
@@ -484,3 +485,7 @@ class Stepper:
         k, n = C.c_int(), C.c_int()
         self._ck(self._L.fibhip_launch_plan(self._h, C.byref(k), C.byref(n)))
         return k.value, n.value
+
+    def ticks_per_launch(self):
+        """consecutive ticks one launch covers (Courtemanche, fast policy, one device: 3; otherwise 1)"""
+        return self._ck(self._L.fibhip_ticks_per_launch(self._h))

@@ -205,6 +205,10 @@ struct Variant {
     {MID, MODE, 1, 0, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, false>},        \
     {MID, MODE, 1, 1, K, TX, TY, NT, launch_tick<MODEL, Fast, MODE, K, TX, TY, NT, true>}
 
+#define FS2(MODEL, MID, MODE, K, TX, TY, R)                                                        \
+    {MID, MODE, 1, 0, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, false>},      \
+    {MID, MODE, 1, 1, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, true>}
+
 // strip kernels are listed with NT = -R (rows per wave)
 #define S4(MODEL, MID, MODE, K, TX, TY, R)                                                         \
     {MID, MODE, 0, 0, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, false>},     \
@@ -314,6 +318,26 @@ static const Variant g_variants[] = {
     F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 1, 64, 4, 256),
     F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 1, 64, 8, 256),
     F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FASTSLOW, 1, 64, 4, 256),
+    // two and three consecutive fast ticks in one launch (fibhip_step defers ticks: see tick_multi); first entry of
+    // each K = default, the others for tools/sweep.py (FIBHIP_COURT_MULTI2 / FIBHIP_COURT_MULTI3 = "TX,TY,NT")
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 20, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 14, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 16, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 18, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 22, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 24, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 25, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 28, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 26, 3),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 58, 12, 1),
+    F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 3, 32, 32, 256),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 14, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 12, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 16, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 18, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 22, 2),
+    FS2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 60, 30, 2),
+    F2(CourtAgg, VM_COURT_AGG, CourtAgg::MODE_FAST, 2, 64, 16, 256),
     // ---- court_ultra.py with the ultra-slow `_us_` gate: 22 variables, single rate ----
     V4(CourtemancheUS, FIBHIP_COURT_US, CourtemancheUS::MODE_ALL, 1, 64, 4, 256),
 #endif
@@ -369,7 +393,9 @@ struct fibhip_ctx {
     long launches, t_launches0;
     int own0, own1;         // owned local rows
     bool whole_in_edges;    // this tick's last launch was issued entirely by step_edges
-    bool pending;           // fibhip_step's last tick has not been launched yet (see lazy_fusable)
+    int pending;            // ticks fibhip_step has accepted but not launched yet (see fibhip_step)
+    int multi_max;          // up to this many consecutive ticks go into one launch (1 = never; CourtAgg: 3)
+    std::vector<PlanItem> plan_multi[4];    // [T]: the one-launch plan of T ticks, T = 2..multi_max
     fibhip_module *mod;     // FIBHIP_CUSTOM on a run-time module (fibhip_module_load), or null
     bool tuned;             // the plan has been checked against the other tile shapes on this very geometry (autotune)
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
@@ -590,6 +616,22 @@ static int build_plan(fibhip_ctx *h)
         const Variant *v = find_variant(h, 1, want1, Courtemanche::MODE_FASTSLOW);
         if (v && (h->d.height - 1) % v->TY != 0 && (h->d.width - 1) % v->TX != 0) h->fused_fn = v->fn;
     }
+    // Courtemanche on aggregates: one tick is one sub-step and moves 16 arrays for ~300 instructions per cell, so
+    // two or three consecutive ticks are blocked in time like the sub-steps of a Fenton tick (fibhip_step defers
+    // ticks until a launch is full; every entry point that observes the state launches what is pending first)
+    h->multi_max = 1;
+    for (int T = 2; T <= 3; ++T) h->plan_multi[T].clear();
+    if (h->use_agg && h->mode == CourtAgg::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 && !getenv("FIBHIP_NO_MULTI")) {
+        for (int T = 2; T <= 3; ++T) {
+            int w[3];
+            const char *e = getenv(T == 2 ? "FIBHIP_COURT_MULTI2" : "FIBHIP_COURT_MULTI3");
+            const bool have = e && sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]) == 3;
+            const Variant *v = find_variant(h, T, have ? w : nullptr, CourtAgg::MODE_FAST);
+            if (!v) break;
+            h->plan_multi[T].push_back({v->K, v->fn, v->TY, v->TX, v});
+            h->multi_max = T;
+        }
+    }
 #endif
     return 0;
 }
@@ -739,7 +781,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     for (int v = 0; v < FIB_MAXVAR; ++v) h->cur[v] = h->nxt[v] = 0;
     h->phase_of_tick = 0;
     h->launches = 0;
-    h->pending = false;
+    h->pending = 0;
+    h->multi_max = 1;
     h->fused_fn = nullptr;
     h->comm = nullptr;
     h->tuned = false;
@@ -1018,9 +1061,65 @@ static int check_ready(fibhip_ctx *h)
 // writes what the real launch overwrites) and keeps the fastest.  All candidates are bit-identical in their results
 // (tests/test_gpu_parity.py::test_fenton_fusion_depths_bit_identical), so the choice changes speed only — ranks of
 // a sharded grid may choose differently.  FIBHIP_AUTOTUNE=0, FIBHIP_VARIANT or FIBHIP_K switch it off.
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr);
+
+// Courtemanche on aggregates: recompute them if the state was written from outside since they were formed
+static int refresh_agg(fibhip_t h)
+{
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    if (h->use_agg && h->agg_dirty) {
+        if (int rc = run_pointwise_mode(h, launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_AGG>, nullptr)) return rc;
+        h->agg_dirty = false;
+    }
+#endif
+    return 0;
+}
+
+// Courtemanche on aggregates: which tile shape for the launches of two and of three ticks, on this very geometry
+static int autotune_multi(fibhip_ctx *h)
+{
+#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
+    if (const char *e = getenv("FIBHIP_AUTOTUNE"))
+        if (atoi(e) == 0) return 0;
+    if (int rc = refresh_agg(h)) return rc;                       // time the kernels on real values
+    const int phase = h->has_phase ? 1 : 0;
+    const long launches0 = h->launches;
+    for (int T = 2; T <= h->multi_max; ++T) {
+        if (getenv(T == 2 ? "FIBHIP_COURT_MULTI2" : "FIBHIP_COURT_MULTI3")) continue;
+        float best_ms = 1e30f;
+        for (int i = 0; i < g_nvariants; ++i) {
+            const Variant &v = g_variants[i];
+            if (v.model != VM_COURT_AGG || v.mode != CourtAgg::MODE_FAST || v.fast != 1 || v.phase != phase || v.K != T) continue;
+            const PlanItem it = {v.K, v.fn, v.TY, v.TX, &v};
+            float ms_best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                HIPCHK(hipEventRecord(h->ev_t0, h->s0));
+                LaunchCtx c;
+                int nxt[FIB_MAXVAR];
+                fill_ptrs(h, c, T, h->cur, nxt);                  // current slab -> other slab: the state stays put
+                c.sub0 = 0;
+                if (int rc = launch_range(h, h->s0, it, c, 0, h->d.height)) return rc;
+                HIPCHK(hipEventRecord(h->ev_t1, h->s0));
+                HIPCHK(hipEventSynchronize(h->ev_t1));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+                if (rep > 0 && ms < ms_best) ms_best = ms;
+            }
+            if (ms_best < best_ms) {
+                best_ms = ms_best;
+                h->plan_multi[T].assign(1, it);
+            }
+        }
+    }
+    h->launches = launches0;
+#endif
+    return 0;
+}
+
 static int autotune(fibhip_ctx *h)
 {
     h->tuned = true;
+    if (h->use_agg && h->multi_max > 1) return autotune_multi(h);
     if ((h->d.model != FIBHIP_FENTON4V && h->d.model != FIBHIP_BR) || (h->d.flags & FIBHIP_ZEROPAD) || h->spt < 2) return 0;
     if (getenv("FIBHIP_VARIANT") || getenv("FIBHIP_K")) return 0;
     if (const char *e = getenv("FIBHIP_AUTOTUNE"))
@@ -1082,20 +1181,6 @@ static int autotune(fibhip_ctx *h)
     }
     h->plan = best_plan;
     h->launches = launches0;
-    return 0;
-}
-
-static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr);
-
-// Courtemanche on aggregates: recompute them if the state was written from outside since they were formed
-static int refresh_agg(fibhip_t h)
-{
-#if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
-    if (h->use_agg && h->agg_dirty) {
-        if (int rc = run_pointwise_mode(h, launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_AGG>, nullptr)) return rc;
-        h->agg_dirty = false;
-    }
-#endif
     return 0;
 }
 
@@ -1199,12 +1284,32 @@ static int tick_now(fibhip_t h)
     return commit_impl(h);
 }
 
-// launch the tick fibhip_step left pending; every entry point that observes or changes the state calls this first
+// T consecutive ticks as one launch (T <= multi_max)
+static int tick_multi(fibhip_t h, int T)
+{
+    if (T <= 1) return tick_now(h);
+    h->plan.swap(h->plan_multi[T]);
+    const int rc = tick_now(h);
+    h->plan.swap(h->plan_multi[T]);
+    return rc;
+}
+
+// launch `n` of the ticks fibhip_step has deferred, the fewest launches first
+static int launch_pending(fibhip_t h, int n)
+{
+    while (n > 0) {
+        const int T = imin(h->multi_max, n);
+        h->pending -= T;
+        n -= T;
+        if (int rc = tick_multi(h, T)) return rc;
+    }
+    return 0;
+}
+
+// launch the ticks fibhip_step left pending; every entry point that observes or changes the state calls this first
 static int flush(fibhip_t h)
 {
-    if (!h->pending) return 0;
-    h->pending = false;
-    return tick_now(h);
+    return launch_pending(h, h->pending);
 }
 
 extern "C" int fibhip_step_edges(fibhip_t h)
@@ -1230,15 +1335,22 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
 {
     NEED(h);
     if (nticks < 0) return fail(FIBHIP_EINVAL, "negative tick count");
-    FLUSH(h);
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step inside an open tick");
-    for (int t = 0; t < nticks; ++t) {
-        if (t + 1 == nticks && h->fused_fn) {             // the last tick waits for the next call: it may be a
-            if (int rc = check_ready(h)) return rc;       // step_slow, and then both are one launch
-            h->pending = true;
-            break;
-        }
-        if (int rc = tick_now(h)) return rc;
+    // Ticks are accepted here and launched when a launch is full: up to multi_max ticks go into one kernel (CourtAgg),
+    // and the last accepted tick is held back when the next call may be a step_slow, which then rides on its launch
+    // (fused_fn).  Whatever is held back is launched by the next entry point that observes or changes the state.
+    const int reserve = h->fused_fn ? 1 : 0;
+    const int cap = (h->multi_max > 1 ? h->multi_max - 1 : 0) + reserve;
+    if (cap > 0 && nticks > 0) {
+        if (int rc = check_ready(h)) return rc;           // a deferred tick must not fail later, in someone else's call
+        if (!h->tuned)                                    // (here, not inside a launch: the plans are being chosen)
+            if (int rc = autotune(h)) return rc;
+    }
+    h->pending += nticks;
+    while (h->pending > cap) {
+        const int T = imin(h->multi_max, h->pending - reserve);
+        h->pending -= T;
+        if (int rc = tick_multi(h, T)) return rc;
     }
     return 0;
 }
@@ -1308,8 +1420,9 @@ extern "C" int fibhip_step_mode(fibhip_t h, int mode)
 #if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
     if (h->d.model == FIBHIP_COURT && mode == Courtemanche::MODE_SLOW) {
         if (h->d.flags & FIBHIP_ALLVARS) return fail(FIBHIP_EINVAL, "step_slow: handle was created with FIBHIP_ALLVARS");
-        if (h->pending && h->fused_fn) {                  // tick + slow as one launch
-            h->pending = false;
+        if (h->pending && h->fused_fn) {                  // the last deferred tick + slow as one launch
+            if (int rc = launch_pending(h, h->pending - 1)) return rc;
+            h->pending = 0;
             const launch_fn plain = h->plan[0].fn;
             h->plan[0].fn = h->fused_fn;
             const int rc = tick_now(h);
@@ -1771,6 +1884,12 @@ extern "C" int fibhip_halo_due(fibhip_t h)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
     return ends_cycle(h) ? 1 : 0;
+}
+
+extern "C" int fibhip_ticks_per_launch(fibhip_t h)
+{
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    return h->multi_max;
 }
 
 extern "C" int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick)

@@ -241,6 +241,11 @@ int fibhip_court_inter(int device, int n, const float *V, int fast, float *out);
 
 /* introspection for DESIGN/bench: sub-steps fused per launch and launches per tick                      */
 int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick);
+/* Consecutive ticks one launch can cover (1 = every tick is its own launch or launches).  Courtemanche under
+ * FIBHIP_FAST on one device returns 3: fibhip_step() accepts ticks and launches them three at a time, temporally
+ * blocked; whatever has been accepted but not launched is launched by the next call that observes or changes the
+ * state (get/set_state, probe, pace, sync, step_slow ...), so no caller can see the difference.                  */
+int fibhip_ticks_per_launch(fibhip_t h);
 
 const char *fibhip_last_error(void);
 

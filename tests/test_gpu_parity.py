@@ -239,6 +239,44 @@ def test_court_aggregated_fast_tick(gpu_lib, monkeypatch, H, W):
             assert_close(sa[v], sb[v], court_rel(v), 'var %d' % v, scale=COURT_SCALES[v])
 
 
+@pytest.mark.parametrize('H,W', [(70, 66), (65, 64), (33, 200), (3, 5)])
+def test_court_multi_tick_launches_bit_identical(gpu_lib, monkeypatch, H, W):
+    """fibhip_step defers Courtemanche ticks so that up to three consecutive fast ticks run as ONE temporally blocked
+    launch (and the last one still rides on 'slow'): the same arithmetic per cell, so not a bit may differ from one
+    launch per tick (FIBHIP_NO_MULTI=1) — with a pace, a host write and read-backs falling between the ticks"""
+    xs = np.full((H, W), 0.6, np.float32)
+    monkeypatch.delenv('FIBHIP_NO_MULTI', raising=False)
+    a = _court_run(monkeypatch, True, H, W, poke=(26, 11, xs))
+    monkeypatch.setenv('FIBHIP_NO_MULTI', '1')
+    b = _court_run(monkeypatch, True, H, W, poke=(26, 11, xs))
+    for sa, sb in zip(a, b):
+        assert np.array_equal(sa, sb)
+
+
+def test_court_multi_tick_launch_count(gpu_lib, monkeypatch):
+    """ten ticks and a 'slow': three 3-tick launches and the fused tick+slow launch"""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.court import INITIAL
+    monkeypatch.delenv('FIBHIP_NO_MULTI', raising=False)
+    monkeypatch.delenv('FIBHIP_COURT_AGG', raising=False)
+    H, W = 70, 66
+    init = np.empty((21, H, W), np.float32)
+    for i, (_, v) in enumerate(INITIAL):
+        init[i] = v
+    st = _lib.Stepper(_lib.COURT, H, W, 0.1, 0.809, flags=_lib.FAST)
+    st.set_state(-1, init)
+    st.step(1)
+    st.step_slow()                       # (first tick: aggregates formed, then tick + slow)
+    st.sync()
+    st.time_begin()
+    for i in range(10):
+        st.step(1)
+    st.step_slow()
+    ms, launches = st.time_end()
+    assert launches == 4, launches
+    st.close()
+
+
 def test_court_aggregates_follow_host_writes(gpu_lib, monkeypatch):
     """set_state of a slow variable between two ticks: the aggregates are recomputed before the next tick (a stale
     aggregate would keep the old conductance: compare with the plain kernels after the write)"""
