@@ -247,6 +247,8 @@ static const Variant g_variants[] = {
     // that gives every CU at most one tile (or the fewest rounds) for the grid at hand
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 27, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 30, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 36, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 40, 4),
@@ -255,6 +257,10 @@ static const Variant g_variants[] = {
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 27, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 25, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 28, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 31, 3),
+    S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 34, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 32, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 40, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 44, 4),
@@ -283,6 +289,8 @@ static const Variant g_variants[] = {
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 24, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 27, 3),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 28, 3),
+    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 16, 2),
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
@@ -297,6 +305,8 @@ static const Variant g_variants[] = {
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 24, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 27, 3),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 28, 3),
+    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 16, 2),
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults

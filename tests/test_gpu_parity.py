@@ -393,7 +393,8 @@ def run_to(model, ticks, hook=None):
 
 
 # (NT < -32: rows_kernel, potential in registers + DPP taps, with R = -NT - 32 rows per wave)
-FENTON_VARIANTS = ['', '10,44,25,-35', '5,54,21,-35', '10,44,28,-3', '10,44,25,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4',
+FENTON_VARIANTS = ['', '10,44,25,-35', '5,54,21,-35', '10,44,28,-3', '10,44,25,-3', '10,44,27,-3', '10,44,30,-3', '5,54,25,-3',
+                   '5,54,28,-3', '5,54,31,-3', '5,54,34,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4',
                    '10,44,44,-4', '5,54,21,-3', '5,54,23,-3', '5,54,22,-4', '5,54,27,-3', '5,54,32,-4', '5,54,40,-3', '5,54,44,-4',
                    '5,54,56,-4', '2,60,18,-4', '10,32,32,512', '10,32,32,1024', '10,32,32,256', '5,32,32,256', '5,32,32,512',
                    '5,32,16,256', '2,64,16,256', '2,32,32,256', '1,64,16,256', '1,64,4,256']
@@ -488,7 +489,8 @@ def test_fenton_driver_semantics(gpu_lib, golden, policy):
 
 @pytest.mark.parametrize('name', ['br_traj64_direct', 'br_traj64_cheby', 'br_traj64_skip', 'br_traj64_cheby_skip'])
 @pytest.mark.parametrize('policy', POLICIES)
-@pytest.mark.parametrize('variant', ['', '1,64,4,256', '5,32,32,512', '5,54,21,-3', '5,54,21,-2', '3,58,19,-2'])
+@pytest.mark.parametrize('variant', ['', '1,64,4,256', '5,32,32,512', '5,54,21,-3', '5,54,21,-2', '3,58,19,-2', '5,54,28,-3',
+                                     '5,54,16,-2'])
 def test_br_trajectory_64(gpu_lib, golden, name, variant, monkeypatch, policy):
     from fib_tf_amd.br import BeelerReuter
     if variant:

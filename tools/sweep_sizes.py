@@ -16,12 +16,13 @@ def run(model, size, variant=None, k=None):
     best = min(st.time_steps(n)[0] for _ in range(3))
     print('%-7s %5d %-14s plan %-8s %8.2f us/tick %9.0f Mcs/s' % (model, size, variant or ('K=%s'%k if k else 'default'), st.launch_plan(), best*1000/n, m.height*m.width*n*m.dt_per_step/(best*1e-3)/1e6), flush=True)
     st.close()
-FV = ('10,44,25,-3', '10,44,28,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4', '10,44,44,-4', '5,54,21,-3', '5,54,23,-3', '5,54,22,-4',
-      '5,54,27,-3', '5,54,32,-4', '5,54,40,-3', '5,54,44,-4', '5,54,56,-4')
-for size in (384, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1280, 1536, 2048, 4096):
+FV = ('10,44,25,-3', '10,44,27,-3', '10,44,28,-3', '10,44,30,-3', '10,44,32,-4', '10,44,36,-4', '10,44,40,-4', '10,44,44,-4', '5,54,21,-3', '5,54,23,-3', '5,54,22,-4',
+      '5,54,25,-3', '5,54,27,-3', '5,54,28,-3', '5,54,31,-3', '5,54,34,-3', '5,54,32,-4', '5,54,40,-3', '5,54,44,-4', '5,54,56,-4')
+SIZES = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (384, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1280, 1536, 2048, 4096)
+for size in SIZES:
     for v in (None,) + FV:
         run('fenton', size, v)
-for size in (512, 576, 640, 704, 768, 896, 1024):
+for size in ([] if len(sys.argv) > 1 else (512, 576, 640, 704, 768, 896, 1024)):
     for k in (None, 5, 1):
         run('br', size, None, k)
 
