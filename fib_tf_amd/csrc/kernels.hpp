@@ -105,16 +105,19 @@ static FIB_DEV float phase_term(float N, float S, float Wv, float E, float dpy, 
 }
 
 // The Laplacian of the FUSED kernels under the two arithmetic policies.  Exact: the reference's operations, one
-// rounding each (stencil9 / phase_term).  Fast: the same association order with the two scalings (0.5*, -6*) and the
-// phase quotient contracted into FMAs — 13 instructions instead of 19; every fused kernel uses these two functions, so
-// fusion depth and tile shape still never change a bit of the result within a policy.  (The stand-alone array ops
+// rounding each (stencil9 / phase_term).  Fast: re-associated row by row with the scalings (0.5*, -6*) and the phase
+// quotient contracted into FMAs; every fused kernel uses these two functions, so fusion depth and tile shape still
+// never change a bit of the result within a policy.  (The stand-alone array ops
 // IonicModel.laplace / phase_field keep the exact form under both policies.)
 template <class P>
 static FIB_DEV float lap9(float N, float S, float Wv, float E, float NW, float SW, float NE, float SE, float C)
 {
     if constexpr (same_type<P, Fast>::value) {
-        const float l1 = ((N + S) + Wv) + E, d = ((NW + SW) + NE) + SE;
-        return __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
+        // row by row: a(row) = centre + 0.5 (west + east) for the rows above and below, b = (west + east) - 6 centre for
+        // the cell's own row.  The R cells of a lane share these row terms (a of the row below cell r is a of the row
+        // above cell r+2, west + east of a row serves both forms): 19 operations for three cells instead of 24.
+        const float an = __builtin_fmaf(0.5f, NW + NE, N), as = __builtin_fmaf(0.5f, SW + SE, S);
+        return (an + as) + __builtin_fmaf(-6.0f, C, Wv + E);
     } else {
         return stencil9(N, S, Wv, E, NW, SW, NE, SE, C);
     }
@@ -122,8 +125,8 @@ static FIB_DEV float lap9(float N, float S, float Wv, float E, float NW, float S
 template <class P>
 static FIB_DEV float add_phase(float lap, float N, float S, float Wv, float E, float dpy, float dpx, float q4, float r4)
 {
-    if constexpr (same_type<P, Fast>::value)
-        return __builtin_fmaf(__builtin_fmaf(E - Wv, dpx, (S - N) * dpy), r4, lap);
+    if constexpr (same_type<P, Fast>::value)   // (dpx*r4 and dpy*r4 do not change during a launch: formed once, before the step loop)
+        return __builtin_fmaf(E - Wv, dpx * r4, __builtin_fmaf(S - N, dpy * r4, lap));
     else
         return lap + phase_term<P>(N, S, Wv, E, dpy, dpx, q4, r4);
 }
@@ -593,8 +596,9 @@ static FIB_DEV float stencil9_lanes(float N, float S, float C, float dpy, float 
     const float Wv = lane_west(C), E = lane_east(C);
     const float l1 = (ns + Wv) + E, d = (lane_west(ns) + lane_east(N)) + lane_east(S);
     float r;
-    if constexpr (same_type<P, Fast>::value)
-        r = __builtin_fmaf(-6.0f, C, __builtin_fmaf(0.5f, d, l1));
+    if constexpr (same_type<P, Fast>::value)                      // lap9<Fast>'s row-by-row form, the taps by lane shifts
+        r = (__builtin_fmaf(0.5f, lane_west(N) + lane_east(N), N) + __builtin_fmaf(0.5f, lane_west(S) + lane_east(S), S)) +
+            __builtin_fmaf(-6.0f, C, Wv + E);
     else
         r = (l1 + 0.5f * d) - 6.0f * C;
     if (PHASE) r = add_phase<P>(r, N, S, Wv, E, dpy, dpx, q4, r4);
