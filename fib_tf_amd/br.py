@@ -21,6 +21,9 @@ def specialised_library(table32, build=True, verbose=False):
     is neither cached nor buildable here (the caller then stays on the stock library)"""
     import hashlib
     import subprocess
+    alt = os.environ.get('FIBHIP_BR_LIBRARY')           # tuning experiments (tools/ab.sh): another build for this table
+    if alt:
+        return _lib.load(alt)
     h = hashlib.sha1(table32.tobytes())
     for d in _lib.DEPS:
         with open(d, 'rb') as f:
