@@ -1130,7 +1130,9 @@ static int autotune(fibhip_ctx *h)
 {
     h->tuned = true;
     if (h->use_agg && h->multi_max > 1) return autotune_multi(h);
-    if ((h->d.model != FIBHIP_FENTON4V && h->d.model != FIBHIP_BR) || (h->d.flags & FIBHIP_ZEROPAD) || h->spt < 2) return 0;
+    if ((h->d.model != FIBHIP_FENTON4V && h->d.model != FIBHIP_BR && h->d.model != FIBHIP_CUSTOM) ||
+        (h->d.flags & FIBHIP_ZEROPAD) || h->spt < 2)
+        return 0;
     if (getenv("FIBHIP_VARIANT") || getenv("FIBHIP_K")) return 0;
     if (const char *e = getenv("FIBHIP_AUTOTUNE"))
         if (atoi(e) == 0) return 0;
@@ -1143,12 +1145,16 @@ static int autotune(fibhip_ctx *h)
     std::vector<PlanItem> best_plan = heuristic;
     float best_ms = 1e30f;
     bool heuristic_timed = false;
-    for (int i = -1; i < g_nvariants; ++i) {
+    // (a traced model on a run-time module brings its own, short, table: the shapes its generated header asked for)
+    const Variant *tab = h->mod ? h->mod->variants.data() : g_variants;
+    const int ntab = h->mod ? (int)h->mod->variants.size() : g_nvariants;
+    for (int i = -1; i < ntab; ++i) {
         std::vector<PlanItem> trial;
         if (i < 0) {
             trial = heuristic;                                    // the rule-based plan is a candidate like any other
         } else {
-            const Variant &v = g_variants[i];
+            const Variant &v = tab[i];
+            if (v.kind == MK_POINTWISE) continue;
             if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
             // strip kernels of every fusion depth, and the one-sub-step-per-launch tiles
             const bool strip = v.NT < 0 && v.NT > -32 && v.K >= 2, single = v.NT > 0 && v.K == 1;

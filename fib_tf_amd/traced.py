@@ -637,8 +637,10 @@ def generate(programs, nslots, remap, spt):
     K2 = 1
     if fuse and weight < 250:
         K2 = max(d for d in range(1, 6) if K % d == 0)
-    R2 = 4 if n <= 5 else 2
-    TX2, TY2 = 64 - 2 * K2, 8 * R2 - 2 * K2
+    # (a few state arrays: 12 full strips of 3 rows — the waves of a workgroup spread evenly over the four SIMDs —
+    # measured best for the hand-written 4-variable model at 1024^2 .. 4096^2)
+    R2 = 3 if n <= 5 else 2
+    TX2, TY2 = 64 - 2 * K2, (36 - 2 * (K2 - 1)) if n <= 5 else 8 * R2 - 2 * K2
     out = ['// generated by fib_tf_amd/traced.py from a traced model graph — do not edit',
            '// graph weight per sub-step: %d' % weight,
            '#define FIB_CUSTOM_K %d' % (K if fuse else 1),

@@ -43,6 +43,7 @@ for name, model, mid, ticks in (('fv', 'fenton', _lib.FENTON4V, 500), ('ev', 'br
         m = make_model(name, N, N, fast_math=fast)
         m.phase = ph
         m.define()
+        m._ensure_compiled()                # (the generated kernels are built on first use)
         m._stepper.set_state(-1, init)
         tr, tus = rate(m._stepper, ticks)
         tp = m._stepper.launch_plan()
