@@ -28,6 +28,45 @@ class FibhipError(RuntimeError):
     pass
 
 
+# ---- arrays on page-locked host memory ------------------------------------------------------------------------------
+# eval() / image() return ordinary NumPy arrays; behind single-array read-backs sits a small pool of page-locked buffers
+# (fibhip_host_alloc) the device writes directly, which saves the staging copy of fibhip_get_state.  A buffer returns to
+# the pool when the last view of its array is gone; with more than PINNED_MAX arrays alive at once (a caller keeping
+# every frame) further read-backs fall back to pageable arrays.
+PINNED_MAX = 8
+_pinned_free = {}          # nbytes -> [address, ...]
+_pinned_out = [0]
+
+
+def _pinned_release(nbytes, addr):
+    _pinned_out[0] -= 1
+    _pinned_free.setdefault(nbytes, []).append(addr)
+
+
+def _pinned_array(L, shape):
+    import weakref
+    n = int(np.prod(shape))
+    nbytes = 4 * n
+    free = _pinned_free.get(nbytes)
+    if free:
+        addr = free.pop()
+    else:
+        if _pinned_out[0] + sum(len(v) for v in _pinned_free.values()) >= PINNED_MAX:
+            other = next((v for v in _pinned_free.values() if v), None)     # an idle buffer of another size makes room
+            if other is None:
+                return None
+            L.fibhip_host_free(other.pop())
+        p = C.c_void_p()
+        if L.fibhip_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+            return None
+        addr = p.value
+    raw = (C.c_float * n).from_address(addr)
+    _pinned_out[0] += 1
+    f = weakref.finalize(raw, _pinned_release, nbytes, addr)
+    f.atexit = False
+    return np.ctypeslib.as_array(raw).reshape(shape)
+
+
 class Desc(C.Structure):
     _fields_ = [('struct_size', C.c_int), ('model', C.c_int), ('height', C.c_int), ('width', C.c_int),
                 ('dt', C.c_double), ('diff', C.c_double), ('flags', C.c_uint), ('device', C.c_int),
@@ -98,6 +137,9 @@ SYMBOLS = {
     'fibhip_module_load': ([C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ModuleDesc), C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_module_unload': ([C.c_void_p], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
+    'fibhip_get_state_direct': ([_h, C.c_int, _fp], C.c_int),
+    'fibhip_host_alloc': ([C.c_size_t, C.POINTER(C.c_void_p)], C.c_int),
+    'fibhip_host_free': ([C.c_void_p], C.c_int),
     'fibhip_ticks_per_launch': ([_h], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -383,6 +425,11 @@ class Stepper:
 
     def get_state(self, var=-1):
         shape = (self.nvar, self.height, self.width) if var < 0 else (self.height, self.width)
+        if var >= 0:                                    # one array (eval(), image()): straight into page-locked memory
+            out = _pinned_array(self._L, shape)
+            if out is not None:
+                self._ck(self._L.fibhip_get_state_direct(self._h, var, _ptr(out)))
+                return out
         out = np.empty(shape, np.float32)
         self._ck(self._L.fibhip_get_state(self._h, var, _ptr(out)))
         return out

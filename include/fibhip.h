@@ -113,6 +113,12 @@ int fibhip_set_state(fibhip_t h, int var, const float *src);
 
 /* == Variable.eval() (fenton.py:152-153, ionic.py:226-229).  Blocks until preceding ticks are done.     */
 int fibhip_get_state(fibhip_t h, int var, float *dst);
+/* The same read-back without the staging copy: `dst` should be page-locked memory from fibhip_host_alloc (the Python
+ * binding keeps a small pool of such buffers behind the arrays `eval()` / `image()` return: the reference driver reads
+ * the potential back 100 times per simulated second, fenton.py:184-185).                                            */
+int fibhip_get_state_direct(fibhip_t h, int var, float *dst);
+int fibhip_host_alloc(size_t nbytes, void **out);
+int fibhip_host_free(void *p);
 
 /* == constants baked into the graph at define time.  BR + FIBHIP_CHEBY: the 12x9 float32 table `d` of
  * br.py:327 in row order m_inf,h_inf,m_tau,h_tau,xi_inf,j_inf,d_inf,f_inf,xi_tau,j_tau,d_tau,f_tau

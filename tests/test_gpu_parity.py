@@ -990,6 +990,37 @@ def test_court_fused_slow_tick_small_shapes(gpu_lib, monkeypatch):
         assert np.array_equal(out[0], out[1]), (H, W)
 
 
+def test_readback_into_page_locked_arrays(gpu_lib):
+    """single-array read-backs (eval(), image()) land in page-locked buffers of a small pool, written by the device
+    directly (fibhip_get_state_direct); the whole-state read-back takes the staged path: same bytes either way, a
+    buffer is reused only after its array is gone, and beyond _lib.PINNED_MAX live arrays the binding falls back to
+    pageable memory"""
+    import gc
+    from fib_tf_amd import _lib
+    rng = np.random.default_rng(3)
+    H, W = 37, 53
+    init = rng.uniform(0, 1, (4, H, W)).astype(np.float32)
+    st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.5, flags=_lib.FAST)
+    st.set_state(-1, init)
+    whole = st.get_state(-1)
+    assert np.array_equal(whole, init)
+    held = [st.get_state(v % 4) for v in range(_lib.PINNED_MAX + 3)]          # more live arrays than the pool has buffers
+    for v, a in enumerate(held):
+        assert np.array_equal(a, init[v % 4])
+    addrs = {a.ctypes.data for a in held}
+    assert len(addrs) == len(held)                                             # no two live arrays share memory
+    first = held[0].ctypes.data
+    keep = held[1].copy()
+    del held[0]
+    gc.collect()
+    again = st.get_state(2)                                                    # takes the buffer that was just released
+    assert again.ctypes.data == first and np.array_equal(again, init[2])
+    assert np.array_equal(held[0], keep)                                       # the other arrays are untouched
+    st.step(3)
+    assert not np.array_equal(st.get_state(0), init[0])
+    st.close()
+
+
 def test_copy_bandwidth_yardstick(gpu_lib):
     """fibhip_copy_bandwidth: the plain streaming copy bench.py reports next to the roofline peak"""
     from fib_tf_amd import _lib
