@@ -1888,7 +1888,7 @@ extern "C" int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float 
             rc = fail(FIBHIP_EHIP, "copy_bandwidth: allocation failed");
             break;
         }
-        const int grid = 256 * 16;                         // 16 workgroups per CU
+        const unsigned grid = (unsigned)((n + 255) / 256);  // one 16-byte element per thread
         hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n);   // warm-up
         float best = 1e30f;
         for (int r = 0; r < reps; ++r) {
