@@ -149,3 +149,36 @@ def test_court_1024_config4_vs_oracle(gpu_lib, orc):
     for i in range(1, 21):
         sc = max(float(np.abs(ref[i]).max()), 1e-3)
         assert np.abs(got[i].astype(np.float64) - ref[i]).max() <= 2e-5 * sc, m.VAR_NAMES[i]
+
+
+def test_court_1024_ticks_per_launch_invariance(gpu_lib, monkeypatch):
+    """configs[4] at full size under the default policy: three ticks per launch (the shape picked by measurement on this
+    grid), one tick per launch (FIBHIP_NO_MULTI) and the other three-tick shapes of the table leave the same bits — with
+    'slow' every 10th tick, a pace and a read-back falling between the ticks"""
+    from fib_tf_amd.court import Courtemanche
+    out = {}
+    for name, env in (('default', {}), ('one tick per launch', {'FIBHIP_NO_MULTI': '1'}),
+                      ('58x28 strips', {'FIBHIP_COURT_MULTI3': '58,28,-2'}), ('32x32 tiles', {'FIBHIP_COURT_MULTI3': '32,32,256'})):
+        for k in ('FIBHIP_NO_MULTI', 'FIBHIP_COURT_MULTI3'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = Courtemanche(dict(BASE, height=1024, width=1024, diff=0.809))
+        m.add_hole_to_phase_field(512, 512, 60)
+        m.define()
+        m.add_pace_op('s2', 'luq', 10.0)
+        if name == 'default':
+            assert m._stepper.ticks_per_launch() == 3
+
+        def hook(i):
+            if i % 10 == 0:
+                m.fire_op('slow')
+            if i == 13:
+                m.fire_op('s2')
+            if i == 17:
+                m._State['_m_'].eval()
+
+        advance(m, 26, hook)
+        out[name] = state(m)
+    for k, v in out.items():
+        assert np.array_equal(v, out['default']), '%s changes the result' % k
