@@ -138,7 +138,7 @@ class BeelerReuter(IonicModel):
         # compiler the stock library with the table as a kernel argument is used.  config['specialise']=False
         # forces the stock library.
         if self.cheby and getattr(self, 'specialise', True) and self._library is None \
-                and getattr(self, 'engine_factory', None) is None and not os.environ.get('FIBHIP_VARIANT'):
+                and not os.environ.get('FIBHIP_VARIANT'):
             # (FIBHIP_VARIANT = a tuning sweep over kernel shapes only the stock library carries)
             self._library = specialised_library(self._table32())
         return super()._new_stepper(steps_per_tick, shard)

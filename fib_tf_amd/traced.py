@@ -885,7 +885,6 @@ class IonicModel(_HostModel):
         if shard and world > 1:
             st = ShardedStepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
                                 device=self.device, steps_per_tick=steps_per_tick,
-                                engine_factory=getattr(self, 'engine_factory', None),
                                 halo_ticks=getattr(self, 'halo_ticks', 4), library=self._library)
         else:
             st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),

@@ -25,13 +25,23 @@ def run_case(rank, world, port, case, outdir):
                'cheby': case.get('cheby', False), 'skip': case.get('skip', False),
                'halo_ticks': case.get('halo_ticks', 4)}
         if case.get('engine', 'oracle') == 'oracle':
-            cfg['engine_factory'] = OracleEngine         # CPU rehearsal; otherwise the HIP engine on device 0
+            # CPU rehearsal: the product's sharded driver on the oracle-backed test engine.  The engine is a
+            # constructor argument of ShardedStepper, not a configuration key of the models: the test puts it there.
+            import fib_tf_amd.sharded as sharded
+
+            class CpuShardedStepper(sharded.ShardedStepper):
+                def __init__(self, *a, **kw):
+                    kw['engine_factory'] = OracleEngine
+                    kw.pop('library', None)              # (a table-specialised HIP library means nothing to it)
+                    super().__init__(*a, **kw)
+            sharded.ShardedStepper = CpuShardedStepper
+            cfg['specialise'] = False                    # no device code is run: no per-table build either
         else:
             cfg['device'] = 0
         slow_trend = case['model'] in ('court', 'gated')
         if case['model'] in ('ap', 'ms', 'gated', 'mrfhn'):       # traced model files (tests/models/)
             from traced_cases import make_model
-            extra = {k: cfg[k] for k in ('halo_ticks', 'device', 'engine_factory') if k in cfg}
+            extra = {k: cfg[k] for k in ('halo_ticks', 'device') if k in cfg}
             m = make_model(case['model'], H, W, case['hole'], **extra)
         else:
             cls = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']]

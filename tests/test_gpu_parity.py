@@ -120,9 +120,10 @@ def test_br_single_step(gpu_lib, golden, cheby, n, policy):
         want = f['%s1_%s_n%d' % (k, tag, n)]
         scale = {'V': 120.0, 'C': 1e-5}.get(k, 1.0)
         tol = STEP_TOL[policy]
-        if cheby and policy == 'fast':
+        if cheby and policy == 'fast' and k == 'H':
             # the fast policy evaluates the degree-8 sums with fused multiply-adds: other rounding points than the
-            # reference's, amplified ~1e2 by the sums (the h/j fits are poorly conditioned, br.py:289-301)
+            # reference's, amplified ~1e2 by the sums; only the h gate's fit is conditioned badly enough to show
+            # (br.py:289-301; measured 6.9e-5, every other variable <= 1.3e-5: tools/br_step_error.py)
             tol = 1e-4
         assert_close(o, want, tol, 'br %s %s n=%d [%s]' % (tag, k, n, policy), scale=scale)
         if n == 0 and k in ('J', 'D', 'F', 'XI'):      # solve(state, 0) carries the slow gates over: bit for bit
