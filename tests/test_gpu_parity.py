@@ -278,6 +278,70 @@ def test_court_multi_tick_launch_count(gpu_lib, monkeypatch):
     st.close()
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_court_deferred_ticks_random_call_sequences(gpu_lib, monkeypatch, seed):
+    """fibhip_step is an enqueue (ticks wait until a launch is full, the last one for a 'slow' that may follow): whatever
+    the caller does in between — steps of any count, 'slow' at any time, pacing, probes, single-array and whole-state
+    reads and writes, timing brackets, sync — must see and leave exactly what one launch per tick leaves.  Random call
+    sequences, compared call by call with the undeferred library (FIBHIP_NO_MULTI + FIBHIP_NO_LAZY)."""
+    from fib_tf_amd import _lib
+    from fib_tf_amd.court import INITIAL
+    H, W = 41, 70
+    rng0 = np.random.default_rng(100 + seed)
+    init = np.empty((21, H, W), np.float32)
+    for i, (_, v) in enumerate(INITIAL):
+        init[i] = v
+    init[0] += rng0.uniform(-5, 40, (H, W)).astype(np.float32)
+    phi = rng0.uniform(0.3, 1.0, (H, W)).astype(np.float32)
+
+    def play(deferred):
+        for k in ('FIBHIP_NO_MULTI', 'FIBHIP_NO_LAZY'):
+            if deferred:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, '1')
+        rng = np.random.default_rng(seed)                 # the same sequence both times
+        st = _lib.Stepper(_lib.COURT, H, W, 0.1, 0.809, flags=_lib.FAST)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        seen = []
+        for _ in range(120):
+            op = rng.choice(['step1', 'step1', 'step1', 'stepn', 'slow', 'pace', 'probe', 'get1', 'getall', 'set1', 'sync',
+                             'timed'])
+            if op == 'step1':
+                st.step(1)
+            elif op == 'stepn':
+                st.step(int(rng.integers(0, 9)))
+            elif op == 'slow':
+                st.step_slow()
+            elif op == 'pace':
+                r0, c0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+                st.pace(r0, r0 + 4, c0, c0 + 4, 5.0, -100.0)
+            elif op == 'probe':
+                seen.append(np.float32(st.probe(int(rng.integers(0, 21)), int(rng.integers(0, H)), int(rng.integers(0, W)))))
+            elif op == 'get1':
+                seen.append(st.get_state(int(rng.integers(0, 21))).copy())
+            elif op == 'getall':
+                seen.append(st.get_state(-1))
+            elif op == 'set1':
+                v = int(rng.integers(1, 21))
+                st.set_state(v, (st.get_state(v) * np.float32(0.999)).astype(np.float32))
+            elif op == 'sync':
+                st.sync()
+            else:
+                st.time_begin()
+                st.step(int(rng.integers(1, 6)))
+                st.time_end()
+        seen.append(st.get_state(-1))
+        st.close()
+        return seen
+
+    a, b = play(True), play(False)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), 'observation %d differs' % i
+
+
 def test_court_aggregates_follow_host_writes(gpu_lib, monkeypatch):
     """set_state of a slow variable between two ticks: the aggregates are recomputed before the next tick (a stale
     aggregate would keep the old conductance: compare with the plain kernels after the write)"""
