@@ -417,8 +417,10 @@ struct fibhip_ctx {
     // Courtemanche, fast policy, one device, planar state: the fast tick reads five per-cell aggregates of the slow
     // variables (models.hpp CourtAgg) instead of the variables themselves.  'slow' rewrites them; any other write to the
     // state (set_state) marks them stale and the next tick recomputes them first.
-    float *agg;             // CourtAgg::NAGG arrays of `cells` floats, or null
+    float *agg;             // CourtAgg::NAGG arrays laid out like the state arrays (planar, or row-interleaved at the
+    size_t agg_stride;      // slab's pitch on row-block shards), `agg_stride` floats apart; or null
     bool use_agg, agg_dirty;
+    bool agg_ghost_dirty;   // row-block shards: a halo exchange has rewritten the ghost rows' slow variables
 };
 
 static const void *consts_of(fibhip_ctx *h)
@@ -631,7 +633,8 @@ static int build_plan(fibhip_ctx *h)
     // ticks until a launch is full; every entry point that observes the state launches what is pending first)
     h->multi_max = 1;
     for (int T = 2; T <= 3; ++T) h->plan_multi[T].clear();
-    if (h->use_agg && h->mode == CourtAgg::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 && !getenv("FIBHIP_NO_MULTI")) {
+    if (h->use_agg && h->mode == CourtAgg::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 && !h->d.ghost_top &&
+        !h->d.ghost_bottom && !getenv("FIBHIP_NO_MULTI")) {
         for (int T = 2; T <= 3; ++T) {
             int w[3];
             const char *e = getenv(T == 2 ? "FIBHIP_COURT_MULTI2" : "FIBHIP_COURT_MULTI3");
@@ -799,12 +802,20 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->agg = nullptr;
     h->use_agg = false;
     h->agg_dirty = true;
+    h->agg_ghost_dirty = false;
+    h->agg_stride = 0;
 #if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
     {
+        // A caller-owned slab can be written behind the library's back — except on a row-block shard, whose contract
+        // is that only the ghost rows change, and only in the exchange between step_edges and step_commit.
         const char *e = getenv("FIBHIP_COURT_AGG");
+        const bool shard = desc->ghost_top || desc->ghost_bottom;
         if (desc->model == FIBHIP_COURT && (desc->flags & FIBHIP_FAST) && !(desc->flags & FIBHIP_ALLVARS) &&
-            !desc->ghost_top && !desc->ghost_bottom && h->pitch == desc->width && h->own_slab && !(e && atoi(e) == 0)) {
-            HIPCHK(hipMalloc((void **)&h->agg, (size_t)CourtAgg::NAGG * h->cells * sizeof(float)));
+            (h->own_slab || shard) && !(e && atoi(e) == 0)) {
+            const bool il = h->pitch != desc->width;       // row-interleaved: the aggregates share the slab's row pitch
+            const size_t floats = il ? (size_t)desc->height * h->pitch : (size_t)CourtAgg::NAGG * h->cells;
+            HIPCHK(hipMalloc((void **)&h->agg, floats * sizeof(float)));
+            h->agg_stride = il ? (size_t)desc->width : h->cells;
             h->use_agg = true;
         }
     }
@@ -1013,7 +1024,7 @@ static void agg_ptrs(const fibhip_ctx *h, LaunchCtx &c)
 #if !defined(FIB_CUSTOM_ONLY) && !defined(FIB_ONLY_BR)
     if (!h->use_agg) return;
     for (int a = 0; a < CourtAgg::NAGG; ++a)
-        c.in[Courtemanche::NVAR + a] = c.out[Courtemanche::NVAR + a] = h->agg + (size_t)a * h->cells;
+        c.in[Courtemanche::NVAR + a] = c.out[Courtemanche::NVAR + a] = h->agg + (size_t)a * h->agg_stride;
 #endif
 }
 
@@ -1110,7 +1121,7 @@ static int check_ready(fibhip_ctx *h)
 // writes what the real launch overwrites) and keeps the fastest.  All candidates are bit-identical in their results
 // (tests/test_gpu_parity.py::test_fenton_fusion_depths_bit_identical), so the choice changes speed only — ranks of
 // a sharded grid may choose differently.  FIBHIP_AUTOTUNE=0, FIBHIP_VARIANT or FIBHIP_K switch it off.
-static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr);
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv = nullptr, int row0 = -1, int row1 = -1);
 
 // Courtemanche on aggregates: recompute them if the state was written from outside since they were formed
 static int refresh_agg(fibhip_t h)
@@ -1119,6 +1130,14 @@ static int refresh_agg(fibhip_t h)
     if (h->use_agg && h->agg_dirty) {
         if (int rc = run_pointwise_mode(h, launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_AGG>, nullptr)) return rc;
         h->agg_dirty = false;
+    }
+    if (h->use_agg && h->agg_ghost_dirty) {               // the rows a neighbour's message has just replaced
+        const launch_fn fn = launch_pointwise<CourtAgg, Fast, CourtAgg::MODE_AGG>;
+        if (h->d.ghost_top)
+            if (int rc = run_pointwise_mode(h, fn, nullptr, 0, h->d.ghost_top)) return rc;
+        if (h->d.ghost_bottom)
+            if (int rc = run_pointwise_mode(h, fn, nullptr, h->d.height - h->d.ghost_bottom, h->d.height)) return rc;
+        h->agg_ghost_dirty = false;
     }
 #endif
     return 0;
@@ -1327,6 +1346,7 @@ static int commit_impl(fibhip_t h)
     if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
     if (split_tick(h, h->plan.back())) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
     memcpy(h->cur, h->nxt, sizeof h->cur);
+    if (h->use_agg && ends_cycle(h)) h->agg_ghost_dirty = true;   // the exchange of this tick replaced the ghost rows
     h->cpos = (h->cpos + 1) % h->cycle;
     h->phase_of_tick = 0;
     return 0;
@@ -1411,7 +1431,7 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
 }
 
 // re-evaluation of the model on the current state, in place, without the stencil: assigns mask(mode)
-static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv)
+static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv, int row0, int row1)
 {
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "step_mode inside an open tick");
     LaunchCtx c;
@@ -1433,6 +1453,10 @@ static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv)
     const int live = (h->cpos == 0 ? h->cycle : h->cycle - h->cpos) * h->spt;
     c.g.r0 = imax(0, h->own0 - (h->d.ghost_top ? live : 0));
     c.g.r1 = imin(h->d.height, h->own1 + (h->d.ghost_bottom ? live : 0));
+    if (row0 >= 0) {                                      // an explicit band of rows instead
+        c.g.r0 = row0;
+        c.g.r1 = row1;
+    }
     c.sub0 = 0;
     HIPCHK(fn(h->s0, c));
     h->launches++;
@@ -1913,7 +1937,8 @@ extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
     FLUSH(h);
-    if (h->use_agg) {                   // the caller may write through the pointer at any time: back to the plain kernels
+    if (h->use_agg && !h->d.ghost_top && !h->d.ghost_bottom) {   // the caller may write through the pointer at any time: back to
+                                                                 // the plain kernels (a shard's ghost rows: see create_impl)
         h->use_agg = false;
         if (int rc = build_plan(h)) return rc;
     }

@@ -88,9 +88,6 @@ def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split,
         monkeypatch.setenv('FIBHIP_SPLIT', '1')
     else:
         monkeypatch.delenv('FIBHIP_SPLIT', raising=False)
-    # Courtemanche under the fast policy: row-block shards run the plain kernels (a halo exchange writes slow variables
-    # behind the single-device path's aggregates), so the bitwise yardstick is the plain single handle
-    monkeypatch.setenv('FIBHIP_COURT_AGG', '0')
     want, trend = single(case)
     out = launch(world, dict(case, engine='hip'), tmp_path)
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
