@@ -184,7 +184,7 @@ static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
 }
 
 constexpr int VM_FENTON_ZP = 100;   // variant-table id of FentonZP (not a fibhip_model: selected by FIBHIP_ZEROPAD)
-constexpr int VM_COURT_AGG = 101;   // variant-table id of CourtAgg (Courtemanche, fast policy, one device: fibhip_ctx::use_agg)
+constexpr int VM_COURT_AGG = 101;   // variant-table id of CourtAgg (Courtemanche, fast policy: fibhip_ctx::use_agg)
 
 struct Variant {
     int model, mode, fast, phase;
@@ -414,7 +414,7 @@ struct fibhip_ctx {
     void *comm;             // ncclComm_t of the direct halo path (fibhip_comm_*), or null
     float *probe_host;      // pinned
     float *stage;           // pinned staging buffer for get_state/set_state (one array), allocated on first use
-    // Courtemanche, fast policy, one device, planar state: the fast tick reads five per-cell aggregates of the slow
+    // Courtemanche, fast policy: the fast tick reads five per-cell aggregates of the slow
     // variables (models.hpp CourtAgg) instead of the variables themselves.  'slow' rewrites them; any other write to the
     // state (set_state) marks them stale and the next tick recomputes them first.
     float *agg;             // CourtAgg::NAGG arrays laid out like the state arrays (planar, or row-interleaved at the

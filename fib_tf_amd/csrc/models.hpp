@@ -550,7 +550,7 @@ using Courtemanche = CourtT<false>;
 using CourtemancheUS = CourtT<true>;
 
 // -------------------------------------------------------------------------------------------------------------------
-// Courtemanche under the fast policy on one device: the fast tick with the slow variables folded.
+// Courtemanche under the fast policy: the fast tick with the slow variables folded.
 // court.py:94-103 assigns V, Na_i, m, h on every tick and the other 17 variables only when the driver fires 'slow'
 // (every 10th tick, court.py:612-617).  Between two 'slow' ops the fast tick needs those 17 only through
 //     S1   = c_to oa^3 oi + Cm g_Ks xs^2          (times V - E_K: i_to + i_Ks,            court.py:193,197)
