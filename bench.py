@@ -532,7 +532,8 @@ def bench_ranks(args):
                                    'S1 + S2; 1 step = 1 tick = %d sub-steps'
                                    % (args.model, H, m.width, world, H // world, m.width,
                                       ' (BASELINE configs[3])' if cfgi == 3 else
-                                      (' (%s scaling of BASELINE configs[1] by rows)' % ('strong' if strong else 'weak')), spt),
+                                      (' (%s scaling of BASELINE configs[%d]\'s model by rows)' % ('strong' if strong else 'weak',
+                                                                                           {'fenton': 1, 'br': 2, 'court': 4}[args.model])), spt),
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
                        'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one point-to-point send/recv pair per '
