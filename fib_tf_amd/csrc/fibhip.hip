@@ -1178,6 +1178,9 @@ static int autotune_multi(fibhip_ctx *h)
                 h->plan_multi[T].assign(1, it);
             }
         }
+        if (getenv("FIBHIP_PRINT_PLAN") && !h->plan_multi[T].empty())
+            fprintf(stderr, "fibhip: %dx%d Courtemanche on aggregates: %d ticks per launch in tiles of %dx%d (%.2f us when chosen)\n",
+                    h->d.height, h->d.width, T, h->plan_multi[T][0].TX, h->plan_multi[T][0].TY, best_ms * 1e3f);
     }
     h->launches = launches0;
 #endif
@@ -1255,6 +1258,10 @@ static int autotune(fibhip_ctx *h)
     }
     h->plan = best_plan;
     h->launches = launches0;
+    if (getenv("FIBHIP_PRINT_PLAN") && !best_plan.empty())
+        fprintf(stderr, "fibhip: %dx%d model %d: %zu launch(es) per tick of K=%d, tile %dx%d, %s (%.2f us per tick when chosen)\n",
+                h->d.height, h->d.width, h->d.model, best_plan.size(), best_plan[0].K, best_plan[0].TX, best_plan[0].TY,
+                best_plan[0].v ? (best_plan[0].v->NT < 0 ? "strips" : "flat tiles") : "rule-based", best_ms * 1e3f);
     return 0;
 }
 
