@@ -1154,30 +1154,33 @@ static int autotune_multi(fibhip_ctx *h)
     const long launches0 = h->launches;
     for (int T = 2; T <= h->multi_max; ++T) {
         if (getenv(T == 2 ? "FIBHIP_COURT_MULTI2" : "FIBHIP_COURT_MULTI3")) continue;
-        float best_ms = 1e30f;
+        std::vector<PlanItem> cand;
         for (int i = 0; i < g_nvariants; ++i) {
             const Variant &v = g_variants[i];
             if (v.model != VM_COURT_AGG || v.mode != CourtAgg::MODE_FAST || v.fast != 1 || v.phase != phase || v.K != T) continue;
-            const PlanItem it = {v.K, v.fn, v.TY, v.TX, &v};
-            float ms_best = 1e30f;
-            for (int rep = 0; rep < 4; ++rep) {
+            cand.push_back({v.K, v.fn, v.TY, v.TX, &v});
+        }
+        std::vector<float> best_of(cand.size(), 1e30f);
+        for (int round = 0; round < 4; ++round)                   // rounds over all candidates: see autotune()
+            for (size_t t = 0; t < cand.size(); ++t) {
                 HIPCHK(hipEventRecord(h->ev_t0, h->s0));
                 LaunchCtx c;
                 int nxt[FIB_MAXVAR];
                 fill_ptrs(h, c, T, h->cur, nxt);                  // current slab -> other slab: the state stays put
                 c.sub0 = 0;
-                if (int rc = launch_range(h, h->s0, it, c, 0, h->d.height)) return rc;
+                if (int rc = launch_range(h, h->s0, cand[t], c, 0, h->d.height)) return rc;
                 HIPCHK(hipEventRecord(h->ev_t1, h->s0));
                 HIPCHK(hipEventSynchronize(h->ev_t1));
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
-                if (rep > 0 && ms < ms_best) ms_best = ms;
+                if (round > 0 && ms < best_of[t]) best_of[t] = ms;
             }
-            if (ms_best < best_ms) {
-                best_ms = ms_best;
-                h->plan_multi[T].assign(1, it);
+        float best_ms = 1e30f;
+        for (size_t t = 0; t < cand.size(); ++t)
+            if (best_of[t] < best_ms) {
+                best_ms = best_of[t];
+                h->plan_multi[T].assign(1, cand[t]);
             }
-        }
         if (getenv("FIBHIP_PRINT_PLAN") && !h->plan_multi[T].empty())
             fprintf(stderr, "fibhip: %dx%d Courtemanche on aggregates: %d ticks per launch in tiles of %dx%d (%.2f us when chosen)\n",
                     h->d.height, h->d.width, T, h->plan_multi[T][0].TX, h->plan_multi[T][0].TY, best_ms * 1e3f);
@@ -1203,36 +1206,37 @@ static int autotune(fibhip_ctx *h)
     const int fast = (h->d.flags & FIBHIP_FAST) ? 1 : 0, phase = h->has_phase ? 1 : 0;
     const std::vector<PlanItem> heuristic = h->plan;
     const long launches0 = h->launches;
-    std::vector<PlanItem> best_plan = heuristic;
-    float best_ms = 1e30f;
-    bool heuristic_timed = false;
     // (a traced model on a run-time module brings its own, short, table: the shapes its generated header asked for)
     const Variant *tab = h->mod ? h->mod->variants.data() : g_variants;
     const int ntab = h->mod ? (int)h->mod->variants.size() : g_nvariants;
-    for (int i = -1; i < ntab; ++i) {
+    std::vector<std::vector<PlanItem>> trials;
+    trials.push_back(heuristic);                                  // the rule-based plan is a candidate like any other
+    for (int i = 0; i < ntab; ++i) {
+        const Variant &v = tab[i];
+        if (v.kind == MK_POINTWISE) continue;
+        if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
+        // strip kernels of every fusion depth, and the one-sub-step-per-launch tiles
+        const bool strip = v.NT < 0 && v.NT > -32 && v.K >= 2, single = v.NT > 0 && v.K == 1;
+        if (!(strip || single) || h->spt % v.K != 0 || v.K > maxghost) continue;
+        if (!heuristic.empty() && heuristic[0].fn == v.fn) continue;
         std::vector<PlanItem> trial;
-        if (i < 0) {
-            trial = heuristic;                                    // the rule-based plan is a candidate like any other
-        } else {
-            const Variant &v = tab[i];
-            if (v.kind == MK_POINTWISE) continue;
-            if (v.model != h->d.model || v.mode != h->mode || v.fast != fast || v.phase != phase) continue;
-            // strip kernels of every fusion depth, and the one-sub-step-per-launch tiles
-            const bool strip = v.NT < 0 && v.NT > -32 && v.K >= 2, single = v.NT > 0 && v.K == 1;
-            if (!(strip || single) || h->spt % v.K != 0 || v.K > maxghost) continue;
-            if (!heuristic.empty() && heuristic[0].fn == v.fn && heuristic_timed) continue;
-            for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX, &v});
-        }
-        if (trial.empty()) continue;
-        h->plan = trial;
-        // the whole tick back to back between one pair of events (the gaps between its launches are part of its
-        // cost), best of three after a warm-up pass (code objects, caches)
-        float ms_tick = 1e30f;
-        bool ok = true;
-        for (int rep = 0; rep < 4 && ok; ++rep) {
+        for (int n = 0; n < h->spt / v.K; ++n) trial.push_back({v.K, v.fn, v.TY, v.TX, &v});
+        trials.push_back(trial);
+    }
+    // One tick of a candidate, back to back between one pair of events (the gaps between its launches are part of its
+    // cost).  The candidates are timed in ROUNDS — every candidate once per round, the first round a warm-up (code
+    // objects, caches), the minimum over the other rounds kept: the clocks of a GPU that has just been idle rise for
+    // many milliseconds, and timing the candidates one after the other would favour whichever come last.
+    std::vector<float> best_of(trials.size(), 1e30f);
+    std::vector<bool> failed(trials.size(), false);
+    for (int round = 0; round < 4; ++round) {
+        for (size_t t = 0; t < trials.size(); ++t) {
+            if (failed[t] || trials[t].empty()) continue;
+            const std::vector<PlanItem> &trial = trials[t];
+            h->plan = trial;
             HIPCHK(hipEventRecord(h->ev_t0, h->s0));
             int sub = 0;
-            for (size_t l = 0; l < trial.size() && ok; ++l) {      // every launch with the rows edges_impl gives it
+            for (size_t l = 0; l < trial.size(); ++l) {           // every launch with the rows edges_impl gives it
                 LaunchCtx c;
                 int nxt[FIB_MAXVAR];
                 fill_ptrs(h, c, trial[l].K, h->cur, nxt);         // ALWAYS current slab -> other slab: the state stays put
@@ -1241,21 +1245,23 @@ static int autotune(fibhip_ctx *h)
                 c.sub0 = sub;
                 int r0, r1;
                 rows_of_launch(h, l, r0, r1);
-                if (launch_range(h, h->s0, trial[l], c, r0, r1)) ok = false;
+                if (launch_range(h, h->s0, trial[l], c, r0, r1)) { failed[t] = true; break; }
                 sub += trial[l].K;
             }
             HIPCHK(hipEventRecord(h->ev_t1, h->s0));
             HIPCHK(hipEventSynchronize(h->ev_t1));
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
-            if (rep > 0 && ms < ms_tick) ms_tick = ms;
-        }
-        if (i < 0) heuristic_timed = true;
-        if (ok && ms_tick < best_ms) {
-            best_ms = ms_tick;
-            best_plan = trial;
+            if (round > 0 && ms < best_of[t]) best_of[t] = ms;
         }
     }
+    std::vector<PlanItem> best_plan = heuristic;
+    float best_ms = 1e30f;
+    for (size_t t = 0; t < trials.size(); ++t)
+        if (!failed[t] && !trials[t].empty() && best_of[t] < best_ms) {
+            best_ms = best_of[t];
+            best_plan = trials[t];
+        }
     h->plan = best_plan;
     h->launches = launches0;
     if (getenv("FIBHIP_PRINT_PLAN") && !best_plan.empty())
