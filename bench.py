@@ -336,6 +336,9 @@ def bench_single(args):
                                '1 step = 1 run() tick = %d sub-steps' % (
                                    args.model, m.height, m.width, {'fenton': 1, 'br': 2, 'court': 4}[args.model], spt),
                    'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
+                   'ticks_per_launch': st.ticks_per_launch(),
+                   'tile': '%dx%d cells, %s (chosen by measurement on the first tick)' % (
+                       (lambda t: (t[0], t[1], ('%d rows per wave' % t[2]) if t[2] > 0 else ('%d threads' % -t[2])))(st.plan_tile())),
                    'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
                    'parallelism': 'single device', 'setup_ticks': args.setup + 1,
                    'timing': 'median of %d regions of %d ticks' % (args.repeats, args.steps)},

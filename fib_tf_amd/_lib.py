@@ -141,6 +141,7 @@ SYMBOLS = {
     'fibhip_host_alloc': ([C.c_size_t, C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_host_free': ([C.c_void_p], C.c_int),
     'fibhip_ticks_per_launch': ([_h], C.c_int),
+    'fibhip_plan_tile': ([_h, _ip, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
 
@@ -532,6 +533,12 @@ class Stepper:
         k, n = C.c_int(), C.c_int()
         self._ck(self._L.fibhip_launch_plan(self._h, C.byref(k), C.byref(n)))
         return k.value, n.value
+
+    def plan_tile(self):
+        """(tile width, tile height, rows per wave of a strip kernel | -threads of a flat tile kernel) of the dominant launch"""
+        w, t, r = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.fibhip_plan_tile(self._h, C.byref(w), C.byref(t), C.byref(r)))
+        return w.value, t.value, r.value
 
     def ticks_per_launch(self):
         """consecutive ticks one launch covers (Courtemanche, fast policy, one device: 3; otherwise 1)"""

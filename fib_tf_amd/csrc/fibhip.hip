@@ -1979,6 +1979,17 @@ extern "C" int fibhip_halo_due(fibhip_t h)
     return ends_cycle(h) ? 1 : 0;
 }
 
+extern "C" int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_per_wave)
+{
+    if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    if (h->plan.empty()) return fail(FIBHIP_EINVAL, "no plan");
+    const PlanItem &it = (h->multi_max > 1 && !h->plan_multi[h->multi_max].empty()) ? h->plan_multi[h->multi_max][0] : h->plan[0];
+    if (tile_w) *tile_w = it.TX;
+    if (tile_h) *tile_h = it.TY;
+    if (rows_per_wave) *rows_per_wave = it.v ? -it.v->NT : 0;
+    return 0;
+}
+
 extern "C" int fibhip_ticks_per_launch(fibhip_t h)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");

@@ -247,6 +247,9 @@ int fibhip_court_inter(int device, int n, const float *V, int fast, float *out);
 
 /* introspection for DESIGN/bench: sub-steps fused per launch and launches per tick                      */
 int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick);
+/* ... and the tile of the first launch: width, height, and rows per wave (strip kernels) or -threads per workgroup
+ * (flat tile kernels)                                                                                              */
+int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_per_wave);
 /* Consecutive ticks one launch can cover (1 = every tick is its own launch or launches).  Courtemanche under
  * FIBHIP_FAST on one device returns 3: fibhip_step() accepts ticks and launches them three at a time, temporally
  * blocked; whatever has been accepted but not launched is launched by the next call that observes or changes the
