@@ -151,10 +151,10 @@ static FIB_DEV float expm1_rf(float x)
     const float s = __builtin_ldexpf(1.0f, (int)n);
     return __builtin_fmaf(s, q, s - 1.0f);
 }
-// tanh for the rounding-faithful policy: branch-free, <= 1.4 ulp of the true tanh over the whole float32 range
-// (tools/ubench/tanh_test.c: 32 M samples; glibc's tanhf: 2.2 ulp, the float32 tanh TensorFlow's CPU kernels use is a
-// rational approximation of a few ulp too) at ~23 instructions and two transcendental issues, where ocml's tanhf
-// runs both of its divergent branches at ~4x that.
+// tanh for the rounding-faithful policy: branch-free, <= 1.5 ulp of the true tanh over the whole float32 range,
+// measured on the device (tools/ubench/acc_rf.hip: 22 M arguments per sign; glibc's tanhf: 2.2 ulp, the float32 tanh
+// TensorFlow's CPU kernels use is a rational approximation of a few ulp too) at ~23 instructions and two
+// transcendental issues, where ocml's tanhf runs both of its divergent branches at ~4x that.
 //   |x| < 0.625:  x + x*z*P(z), z = x^2              (Cephes tanhf's polynomial)
 //   otherwise:    1 - 2/(e + 1), e = exp(2|x|) by exp_core above, the quotient by v_rcp_f32 + one Newton step
 static FIB_DEV float tanh_rf(float x)
