@@ -6,11 +6,13 @@
 // There is no CPU path in this library.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -46,6 +48,13 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 // kernel variants
 // ------------------------------------------------------------------------------------------
+constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
+constexpr int AT_MT_TICKS = 4;           // autotune times a multi-tick candidate as one launch of this many ticks
+constexpr int MT_MAX_TILES = 1024;        // epoch words allocated per handle (only grids of <= ncu tiles use them)
+static const char *const MT_DEAD_MSG =
+    "a multi-tick launch gave up: a tile waited 2 s for a neighbouring tile (were all workgroups resident? is another "
+    "process holding the GPU?); the state of this handle is void — FIBHIP_MT=0 runs one launch per tick";
+
 constexpr int FIB_MAXVAR = 26;   // CourtAgg: 21 state arrays + 5 aggregates (CourtemancheUS: 22)
 
 struct LaunchCtx {
@@ -58,6 +67,7 @@ struct LaunchCtx {
     // a kernel of a code object loaded at run time (fibhip_module_load) instead of one linked into this library
     hipFunction_t kern;
     int kind, K, TX, TY, NT, nvar, consts_bytes;
+    MtArgs mt;                      // launch_strip_mt only: the ticks of this launch and what its tiles exchange through
 };
 
 typedef hipError_t (*launch_fn)(hipStream_t, const LaunchCtx &);
@@ -100,6 +110,27 @@ static hipError_t launch_strip(hipStream_t st, const LaunchCtx &c)
     const int grid = ((g.ntiles + 7) / 8) * 8;
     hipLaunchKernelGGL((strip_kernel<M, P, MODE, K, TX, TY, R, PHASE>), dim3(grid), dim3(NT), 0, st, g, pt, c.ph,
                        *static_cast<const typename M::Consts *>(c.consts), c.sub0);
+    return hipGetLastError();
+}
+
+// the strip kernel advancing c.mt.nticks ticks in one launch; the caller has checked that all tiles can be resident
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+static hipError_t launch_strip_mt(hipStream_t st, const LaunchCtx &c)
+{
+    Geo g = c.g;
+    g.tiles_x = (g.W + TX - 1) / TX;
+    g.ty_a = (g.r1 > g.r0) ? (g.r1 - g.r0 + TY - 1) / TY : 0;
+    g.ntiles = g.tiles_x * g.ty_a;                  // (one band: the whole, unsharded grid)
+    if (g.ntiles <= 0) return hipSuccess;
+    PtrTab<M::NVAR> pt;
+    for (int v = 0; v < M::NVAR; ++v) {
+        pt.in[v] = c.in[v];
+        pt.out[v] = c.out[v];
+    }
+    constexpr int NT = 64 * ((TY + 2 * (K - 1) + R - 1) / R);
+    const int grid = ((g.ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((strip_mt_kernel<M, P, MODE, K, TX, TY, R, PHASE>), dim3(grid), dim3(NT), 0, st, g, pt, c.ph,
+                       *static_cast<const typename M::Consts *>(c.consts), c.sub0, c.mt);
     return hipGetLastError();
 }
 
@@ -192,6 +223,7 @@ struct Variant {
     launch_fn fn;
     hipFunction_t kern = nullptr;   // run-time module kernels only (fn == launch_module)
     int kind = 0;
+    launch_fn fn_mt = nullptr;      // the same shape advancing several ticks per launch (strip_mt_kernel), or null
 };
 
 #define V4(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
@@ -215,6 +247,17 @@ struct Variant {
     {MID, MODE, 0, 1, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, true>},      \
     {MID, MODE, 1, 0, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, false>},      \
     {MID, MODE, 1, 1, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, true>}
+
+// strip kernels that also exist as multi-tick launches (K = the model's sub-steps per tick)
+#define S4M(MODEL, MID, MODE, K, TX, TY, R)                                                        \
+    {MID, MODE, 0, 0, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, false>, nullptr, 0,  \
+     launch_strip_mt<MODEL, Exact, MODE, K, TX, TY, R, false>},                                    \
+    {MID, MODE, 0, 1, K, TX, TY, -(R), launch_strip<MODEL, Exact, MODE, K, TX, TY, R, true>, nullptr, 0,   \
+     launch_strip_mt<MODEL, Exact, MODE, K, TX, TY, R, true>},                                     \
+    {MID, MODE, 1, 0, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, false>, nullptr, 0,   \
+     launch_strip_mt<MODEL, Fast, MODE, K, TX, TY, R, false>},                                     \
+    {MID, MODE, 1, 1, K, TX, TY, -(R), launch_strip<MODEL, Fast, MODE, K, TX, TY, R, true>, nullptr, 0,    \
+     launch_strip_mt<MODEL, Fast, MODE, K, TX, TY, R, true>}
 
 // rows kernels (potential in registers, DPP taps) are listed with NT = -(32 + R)
 #define W4(MODEL, MID, MODE, K, TX, TY, R)                                                         \
@@ -245,14 +288,14 @@ static const Variant g_variants[] = {
     // ---- Fenton 4v ----
     // K = 10 (the whole tick in one launch) and K = 5 strips of growing tile height: build_plan picks the shape
     // that gives every CU at most one tile (or the fewest rounds) for the grid at hand
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 27, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 30, 3),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 36, 4),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 40, 4),
-    S4(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 44, 4),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 25, 3),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 28, 3),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 27, 3),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 30, 3),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 32, 4),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 36, 4),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 40, 4),
+    S4M(Fenton, FIBHIP_FENTON4V, 0, 10, 44, 44, 4),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 21, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 23, 3),
     S4(Fenton, FIBHIP_FENTON4V, 0, 5, 54, 22, 4),
@@ -286,12 +329,12 @@ static const Variant g_variants[] = {
     V4(FentonZP, VM_FENTON_ZP, 0, 1, 64, 4, 256),
 #endif
     // ---- Beeler-Reuter (mode 0 direct gates, 1 Chebyshev) ----
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 24, 2),
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 27, 3),
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 28, 3),
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 16, 2),
-    S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 40, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 24, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 27, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 28, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 16, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 0, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 0, 5, 54, 21, 3),
@@ -302,12 +345,12 @@ static const Variant g_variants[] = {
     V4(BeelerReuter, FIBHIP_BR, 0, 5, 32, 32, 512),
     V4(BeelerReuter, FIBHIP_BR, 0, 1, 64, 16, 256),
 #endif
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 24, 2),
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 27, 3),
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 28, 3),
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 16, 2),
-    S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 40, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 24, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 27, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 28, 3),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 16, 2),
+    S4M(BeelerReuter, FIBHIP_BR, 1, 5, 54, 40, 3),
     V4(BeelerReuter, FIBHIP_BR, 1, 1, 64, 4, 256),
 #ifndef FIB_ONLY_BR                     // tuning alternatives (tools/sweep.py); a specialised build keeps the two defaults
     S4(BeelerReuter, FIBHIP_BR, 1, 5, 54, 21, 3),
@@ -385,7 +428,7 @@ struct fibhip_ctx {
     bool own_s0;
     float *slab[2];
     bool own_slab;
-    float *phase3;          // dpy | dpx | q4 | r4, each `cells` floats
+    float *phase3;          // dpy | dpx | q4 | r4 | dpy*r4 | dpx*r4, each `cells` floats
     float *phi_dev;
     bool has_phase;
     int cur[FIB_MAXVAR];            // which slab holds variable v
@@ -406,6 +449,16 @@ struct fibhip_ctx {
     int pending;            // ticks fibhip_step has accepted but not launched yet (see fibhip_step)
     int multi_max;          // up to this many consecutive ticks go into one launch (1 = never; CourtAgg: 3)
     std::vector<PlanItem> plan_multi[4];    // [T]: the one-launch plan of T ticks, T = 2..multi_max
+    // several TICKS per launch (strip_mt_kernel): grids whose tiles are all resident at once, one device, planar slab
+    float *xbuf;            // exchange buffer of 16-byte cells [2][nvar/4][cells], allocated on first use
+    unsigned *epochs;       // one epoch word per tile, 256 bytes apart, + the give-up word behind them
+    unsigned epoch_base;    // value of every epoch word between two launches
+    bool epochs_stale;      // the tiling may have changed since the words were last written: zero them first
+    int mt_max;             // most ticks one launch advances (<= 1: never)
+    int mt_cur;             // ticks the next launch waits for: 1 after any observation of the state, doubling up to mt_max
+    bool mt_inflight;       // a multi-tick launch has been issued since the give-up word was last read
+    bool dead;              // a multi-tick launch gave up waiting: the state is void
+    int ncu;                // compute units of the device
     fibhip_module *mod;     // FIBHIP_CUSTOM on a run-time module (fibhip_module_load), or null
     bool tuned;             // the plan has been checked against the other tile shapes on this very geometry (autotune)
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
@@ -498,6 +551,7 @@ static int build_plan(fibhip_ctx *h)
 {
     h->plan.clear();
     h->tuned = false;
+    h->epochs_stale = true;
     int prefK = 0, want[3], nwant = 0;
     if (const char *e = getenv("FIBHIP_VARIANT")) {
         int k = 0;
@@ -787,7 +841,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
             HIPCHK(hipMemsetAsync(h->slab[i], 0, slab_bytes, h->s0));
         }
     }
-    HIPCHK(hipMalloc((void **)&h->phase3, 4 * h->cells * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&h->phase3, 6 * h->cells * sizeof(float)));
     HIPCHK(hipMalloc((void **)&h->phi_dev, h->cells * sizeof(float)));
     HIPCHK(hipHostMalloc((void **)&h->probe_host, 64, hipHostMallocDefault));
     h->has_phase = false;
@@ -799,6 +853,23 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->fused_fn = nullptr;
     h->comm = nullptr;
     h->tuned = false;
+    h->xbuf = nullptr;
+    h->epochs = nullptr;
+    h->epoch_base = 0;
+    h->epochs_stale = true;
+    h->mt_cur = 1;
+    h->mt_inflight = false;
+    h->dead = false;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, desc->device));
+        h->ncu = prop.multiProcessorCount;
+        // FIBHIP_MT=0 switches multi-tick launches off, FIBHIP_MT_MAX bounds the ticks of one launch
+        const char *e = getenv("FIBHIP_MT"), *em = getenv("FIBHIP_MT_MAX");
+        h->mt_max = (e && atoi(e) == 0) ? 1 : (em && atoi(em) > 0 ? atoi(em) : MT_MAX_TICKS);
+        if (nv % 4 != 0 || interleaved || desc->ghost_top || desc->ghost_bottom || mod || (long long)h->cells * nv * 8 >= (1LL << 31))
+            h->mt_max = 1;
+    }
     h->agg = nullptr;
     h->use_agg = false;
     h->agg_dirty = true;
@@ -824,6 +895,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
 }
 
 extern "C" int fibhip_comm_free(fibhip_t h);
+static void mt_forget(fibhip_ctx *h);
 
 extern "C" int fibhip_destroy(fibhip_t h)
 {
@@ -839,6 +911,9 @@ extern "C" int fibhip_destroy(fibhip_t h)
     if (h->phase3) hipFree(h->phase3);
     if (h->phi_dev) hipFree(h->phi_dev);
     if (h->agg) hipFree(h->agg);
+    if (h->xbuf) hipFree(h->xbuf);
+    if (h->epochs) hipFree(h->epochs);
+    mt_forget(h);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->stage) hipHostFree(h->stage);
     if (h->ev_main) hipEventDestroy(h->ev_main);
@@ -850,6 +925,67 @@ extern "C" int fibhip_destroy(fibhip_t h)
     delete h;
     return 0;
 }
+
+// ---- host-visible waits ---------------------------------------------------------------------------------
+// A blocking hipStreamSynchronize parks the thread on an interrupt: 5-10 us until it runs again, a tenth of a 20-tick
+// region of the 512x512 benchmark and a third of one image() read-back.  Poll instead for as long as short waits last
+// (FIBHIP_SPIN_US, default 2000 us; 0 = always block), then block.
+static long spin_us()
+{
+    static const long v = [] {
+        const char *e = getenv("FIBHIP_SPIN_US");
+        return e ? atol(e) : 2000L;
+    }();
+    return v;
+}
+static hipError_t wait_stream(hipStream_t s)
+{
+    const long lim = spin_us();
+    if (lim <= 0) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();                                  // hipErrorNotReady is not an error to report later
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(lim)) return hipStreamSynchronize(s);
+    }
+}
+static hipError_t wait_event(hipEvent_t ev)
+{
+    const long lim = spin_us();
+    if (lim <= 0) return hipEventSynchronize(ev);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(lim)) return hipEventSynchronize(ev);
+    }
+}
+
+// wait for everything enqueued on the handle's stream; reports a multi-tick launch that gave up (strip_mt_kernel)
+static int sync_s0(fibhip_ctx *h)
+{
+    const bool look = h->mt_inflight && h->epochs;
+    if (look)
+        HIPCHK(hipMemcpyAsync(h->probe_host + 8, h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(wait_stream(h->s0));
+    if (look) {
+        h->mt_inflight = false;
+        unsigned gave_up;
+        memcpy(&gave_up, h->probe_host + 8, sizeof gave_up);
+        if (gave_up) {
+            h->dead = true;
+            return fail(FIBHIP_EHIP, "%s", MT_DEAD_MSG);
+        }
+    }
+    return 0;
+}
+#define SYNC_S0(h)                                                                                 \
+    do {                                                                                           \
+        if (int rc_ = sync_s0(h)) return rc_;                                                      \
+    } while (0)
 
 static Geo base_geo(const fibhip_ctx *h)
 {
@@ -870,6 +1006,7 @@ static Geo base_geo(const fibhip_ctx *h)
 #define NEED(h)                                                  \
     do {                                                         \
         if (!(h)) return fail(FIBHIP_EINVAL, "null handle");     \
+        if ((h)->dead) return fail(FIBHIP_EHIP, "%s", MT_DEAD_MSG);  \
         HIPCHK(hipSetDevice((h)->d.device));                     \
     } while (0)
 
@@ -893,9 +1030,10 @@ extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
     HIPCHK(hipMemcpyAsync(h->phi_dev, phi, h->cells * sizeof(float), hipMemcpyHostToDevice, h->s0));
     const Geo g = base_geo(h);
     hipLaunchKernelGGL(phase_prep_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->phi_dev, h->phase3,
-                       h->phase3 + h->cells, h->phase3 + 2 * h->cells, h->phase3 + 3 * h->cells);
+                       h->phase3 + h->cells, h->phase3 + 2 * h->cells, h->phase3 + 3 * h->cells, h->phase3 + 4 * h->cells,
+                       h->phase3 + 5 * h->cells);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->s0));          // `phi` may be a temporary of the caller
+    SYNC_S0(h);                                   // `phi` may be a temporary of the caller
     h->has_phase = true;
     return build_plan(h);
 }
@@ -914,7 +1052,7 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
                                     (size_t)h->d.width * sizeof(float), (size_t)h->d.width * sizeof(float),
                                     (size_t)h->d.height, hipMemcpyHostToDevice, h->s0));
     }
-    HIPCHK(hipStreamSynchronize(h->s0));
+    SYNC_S0(h);
     // The whole slab restarts the exchange cycle: the caller supplied fresh ghost rows of every array.  ONE array
     // does not: mid-cycle the other arrays' outer ghost rows are stale, so the cycle position stays and the rows
     // of `var` that are still live at this position are the ones the caller's copy has to be right in.
@@ -958,7 +1096,7 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
             HIPCHK(hipMemcpy2DAsync(d, (size_t)h->d.width * sizeof(float), src, (size_t)h->pitch * sizeof(float),
                                     (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
     }
-    HIPCHK(hipStreamSynchronize(h->s0));
+    SYNC_S0(h);
     return 0;
 }
 
@@ -976,7 +1114,7 @@ extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
         HIPCHK(hipMemcpy2DAsync(h->stage, (size_t)h->d.width * sizeof(float),
                                 h->slab[h->cur[v]] + (size_t)v * h->vstride, (size_t)h->pitch * sizeof(float),
                                 (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
-        HIPCHK(hipStreamSynchronize(h->s0));
+        SYNC_S0(h);
         memcpy(dst + (size_t)(v - v0) * h->cells, h->stage, h->cells * sizeof(float));
     }
     return 0;
@@ -1044,6 +1182,8 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     c.ph.dpx = h->phase3 + h->cells;
     c.ph.q4 = h->phase3 + 2 * h->cells;
     c.ph.r4 = h->phase3 + 3 * h->cells;
+    c.ph.pyr = h->phase3 + 4 * h->cells;
+    c.ph.pxr = h->phase3 + 5 * h->cells;
     c.ph.phi = h->phi_dev;
     c.consts = consts_of(h);
 }
@@ -1112,6 +1252,94 @@ static int check_ready(fibhip_ctx *h)
     return 0;
 }
 
+// ---- several ticks per launch (strip_mt_kernel) -----------------------------------------------------------------
+// The tile program of a tick loops over T ticks inside one launch and re-reads only the rim of its compute box from its
+// eight neighbours between two ticks (kernels.hpp, MtArgs).  That needs every tile resident at the same time: the plan
+// must be ONE strip launch per tick whose tiles number at most the device's compute units — and no second such launch
+// of this process on the device at the same time (two half-resident grids would wait for each other until both
+// give up), which g_mt below guarantees.
+static bool mt_eligible(const fibhip_ctx *h, const Variant *v)
+{
+    if (h->mt_max <= 1 || !v || !v->fn_mt || v->K != h->spt || h->use_agg) return false;
+    const long tiles = (long)((h->d.width + v->TX - 1) / v->TX) * ((h->d.height + v->TY - 1) / v->TY);
+    return tiles <= h->ncu && tiles <= MT_MAX_TILES && h->d.device < 16;
+}
+static const Variant *mt_variant(const fibhip_ctx *h)
+{
+    if (h->plan.size() != 1 || h->fused_fn || !mt_eligible(h, h->plan[0].v)) return nullptr;
+    return h->plan[0].v;
+}
+
+static struct {
+    std::mutex mu;
+    fibhip_ctx *owner[16] = {nullptr};              // per device: the handle whose stream carries the last such launch
+} g_mt;
+
+static void mt_forget(fibhip_ctx *h)
+{
+    std::lock_guard<std::mutex> lock(g_mt.mu);
+    for (fibhip_ctx *&o : g_mt.owner)
+        if (o == h) o = nullptr;                     // (fibhip_destroy has drained the stream)
+}
+
+// one launch advancing T >= 2 ticks from the current slab into the other one; `commit`: the handle's state moves with it
+// (autotune times such launches without moving the state)
+static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
+{
+    if (!h->xbuf) {
+        if (hipMalloc((void **)&h->xbuf, 2 * (size_t)h->nvar * h->cells * sizeof(float)) != hipSuccess) {
+            h->xbuf = nullptr;
+            return fail(FIBHIP_ENOMEM, "hipMalloc of the tick-exchange buffer failed");
+        }
+        const size_t words = (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE;
+        if (hipMalloc((void **)&h->epochs, words * sizeof(unsigned)) != hipSuccess) {
+            h->epochs = nullptr;
+            return fail(FIBHIP_ENOMEM, "hipMalloc of the epoch words failed");
+        }
+        h->epochs_stale = true;
+    }
+    if (h->epochs_stale) {                            // first use, or the tiling may have changed: all words equal again
+        HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
+        h->epoch_base = 0;
+        h->epochs_stale = false;
+    }
+    LaunchCtx c;
+    int nxt[FIB_MAXVAR];
+    fill_ptrs(h, c, v->K, h->cur, nxt);
+    c.sub0 = 0;
+    c.g = base_geo(h);
+    c.mt.xb = h->xbuf;
+    c.mt.epoch = h->epochs;
+    c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
+    c.mt.epoch0 = h->epoch_base;
+    c.mt.nticks = T;
+    {
+        std::lock_guard<std::mutex> lock(g_mt.mu);
+        fibhip_ctx *&owner = g_mt.owner[h->d.device];
+        if (owner && owner != h) {                    // behind the other handle's launches, never beside them
+            HIPCHK(hipEventRecord(owner->ev_main, owner->s0));
+            HIPCHK(hipStreamWaitEvent(h->s0, owner->ev_main, 0));
+        }
+        HIPCHK(v->fn_mt(h->s0, c));
+        owner = h;
+    }
+    h->launches++;
+    h->mt_inflight = true;
+    h->epoch_base += (unsigned)(T - 1);               // every tile raised its word once per tick boundary
+    if (commit) memcpy(h->cur, nxt, sizeof nxt);
+    return 0;
+}
+
+static int tick_now(fibhip_t h);
+
+static int tick_mt(fibhip_t h, const Variant *v, int T)
+{
+    if (T <= 1) return tick_now(h);
+    if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step: previous tick not committed");
+    if (int rc = check_ready(h)) return rc;
+    return mt_launch(h, v, T, true);
+}
+
 // Plan selection by measurement (Fenton 4v and Beeler-Reuter).  The K-fused kernels exist in a family of tile shapes
 // (Fenton: K = 10 or 5, tile heights 21..56; Beeler-Reuter: K = 5, heights 21..40, or one sub-step per launch): which
 // one is fastest depends on how the grid's tiles land on the 256 CUs — a launch costs about the
@@ -1170,7 +1398,7 @@ static int autotune_multi(fibhip_ctx *h)
                 c.sub0 = 0;
                 if (int rc = launch_range(h, h->s0, cand[t], c, 0, h->d.height)) return rc;
                 HIPCHK(hipEventRecord(h->ev_t1, h->s0));
-                HIPCHK(hipEventSynchronize(h->ev_t1));
+                HIPCHK(wait_event(h->ev_t1));
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
                 if (round > 0 && ms < best_of[t]) best_of[t] = ms;
@@ -1234,8 +1462,13 @@ static int autotune(fibhip_ctx *h)
             if (failed[t] || trials[t].empty()) continue;
             const std::vector<PlanItem> &trial = trials[t];
             h->plan = trial;
+            // a shape that will run several ticks per launch is timed as that: AT_MT_TICKS ticks in one launch, per tick
+            const bool as_mt = trial.size() == 1 && mt_eligible(h, trial[0].v);
             HIPCHK(hipEventRecord(h->ev_t0, h->s0));
             int sub = 0;
+            if (as_mt) {
+                if (mt_launch(h, trial[0].v, AT_MT_TICKS, false)) failed[t] = true;
+            } else
             for (size_t l = 0; l < trial.size(); ++l) {           // every launch with the rows edges_impl gives it
                 LaunchCtx c;
                 int nxt[FIB_MAXVAR];
@@ -1248,10 +1481,25 @@ static int autotune(fibhip_ctx *h)
                 if (launch_range(h, h->s0, trial[l], c, r0, r1)) { failed[t] = true; break; }
                 sub += trial[l].K;
             }
+            if (failed[t]) {
+                // a shape that cannot be launched here is dropped — audibly, and a failure of the rule-based plan itself is
+                // the caller's error to see
+                (void)hipGetLastError();
+                if (getenv("FIBHIP_PRINT_PLAN"))
+                    fprintf(stderr, "fibhip: %dx%d model %d: candidate K=%d tile %dx%d could not be launched: %s\n", h->d.height,
+                            h->d.width, h->d.model, trial[0].K, trial[0].TX, trial[0].TY, g_err);
+                if (t == 0) {
+                    h->plan = heuristic;
+                    return FIBHIP_EHIP;
+                }
+                HIPCHK(wait_stream(h->s0));
+                continue;
+            }
             HIPCHK(hipEventRecord(h->ev_t1, h->s0));
-            HIPCHK(hipEventSynchronize(h->ev_t1));
+            HIPCHK(wait_event(h->ev_t1));
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+            if (as_mt) ms /= (float)AT_MT_TICKS;
             if (round > 0 && ms < best_of[t]) best_of[t] = ms;
         }
     }
@@ -1263,11 +1511,14 @@ static int autotune(fibhip_ctx *h)
             best_plan = trials[t];
         }
     h->plan = best_plan;
+    h->epochs_stale = true;
     h->launches = launches0;
     if (getenv("FIBHIP_PRINT_PLAN") && !best_plan.empty())
         fprintf(stderr, "fibhip: %dx%d model %d: %zu launch(es) per tick of K=%d, tile %dx%d, %s (%.2f us per tick when chosen)\n",
                 h->d.height, h->d.width, h->d.model, best_plan.size(), best_plan[0].K, best_plan[0].TX, best_plan[0].TY,
-                best_plan[0].v ? (best_plan[0].v->NT < 0 ? "strips" : "flat tiles") : "rule-based", best_ms * 1e3f);
+                best_plan[0].v ? (best_plan[0].v->NT < 0 ? (best_plan.size() == 1 && mt_eligible(h, best_plan[0].v)
+                                                                ? "strips, several ticks per launch" : "strips") : "flat tiles") : "rule-based",
+                best_ms * 1e3f);
     return 0;
 }
 
@@ -1385,6 +1636,16 @@ static int tick_multi(fibhip_t h, int T)
 // launch `n` of the ticks fibhip_step has deferred, the fewest launches first
 static int launch_pending(fibhip_t h, int n)
 {
+    if (n > 0)
+        if (const Variant *v = mt_variant(h)) {
+            while (n > 0) {
+                const int T = imin(h->mt_max, n);
+                h->pending -= T;
+                n -= T;
+                if (int rc = tick_mt(h, v, T)) return rc;
+            }
+            return 0;
+        }
     while (n > 0) {
         const int T = imin(h->multi_max, n);
         h->pending -= T;
@@ -1397,6 +1658,7 @@ static int launch_pending(fibhip_t h, int n)
 // launch the ticks fibhip_step left pending; every entry point that observes or changes the state calls this first
 static int flush(fibhip_t h)
 {
+    h->mt_cur = 1;                                  // the caller is about to look: the next tick starts a new series
     return launch_pending(h, h->pending);
 }
 
@@ -1427,6 +1689,25 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // Ticks are accepted here and launched when a launch is full: up to multi_max ticks go into one kernel (CourtAgg),
     // and the last accepted tick is held back when the next call may be a step_slow, which then rides on its launch
     // (fused_fn).  Whatever is held back is launched by the next entry point that observes or changes the state.
+    // Fenton / Beeler-Reuter on a grid whose tiles are all resident at once: consecutive ticks become ONE launch whose
+    // tiles hand their rims to each other (tick_mt).  A launch goes out as soon as `mt_cur` ticks are waiting — 1 after
+    // any call that observes the state, so the device starts at once, then 2, 4, ... mt_max while the caller keeps
+    // stepping — and takes every waiting tick, up to mt_max.
+    if (h->mt_max > 1 && nticks > 0) {
+        if (int rc = check_ready(h)) return rc;
+        if (!h->tuned)
+            if (int rc = autotune(h)) return rc;
+        if (const Variant *v = mt_variant(h)) {
+            h->pending += nticks;
+            while (h->pending >= h->mt_cur) {
+                const int T = imin(h->pending, h->mt_max);
+                h->pending -= T;
+                if (int rc = tick_mt(h, v, T)) return rc;
+                h->mt_cur = imin(2 * h->mt_cur, h->mt_max);
+            }
+            return 0;
+        }
+    }
     const int reserve = h->fused_fn ? 1 : 0;
     const int cap = (h->multi_max > 1 ? h->multi_max - 1 : 0) + reserve;
     if (cap > 0 && nticks > 0) {
@@ -1561,7 +1842,7 @@ extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "probe inside an open tick");
     HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->vstride + (size_t)row * h->pitch + col,
                           sizeof(float), hipMemcpyDeviceToHost, h->s0));
-    HIPCHK(hipStreamSynchronize(h->s0));
+    SYNC_S0(h);
     *out = *h->probe_host;
     return 0;
 }
@@ -1570,8 +1851,8 @@ extern "C" int fibhip_sync(fibhip_t h)
 {
     NEED(h);
     FLUSH(h);
-    HIPCHK(hipStreamSynchronize(h->s1));
-    HIPCHK(hipStreamSynchronize(h->s0));
+    HIPCHK(wait_stream(h->s1));
+    SYNC_S0(h);
     return 0;
 }
 
@@ -1584,7 +1865,7 @@ extern "C" int fibhip_time_steps(fibhip_t h, int nticks, float *elapsed_ms, int 
     if (int rc = fibhip_step(h, nticks)) return rc;
     FLUSH(h);                                             // the timed region ends after the LAST tick's launch
     HIPCHK(hipEventRecord(h->ev_t1, h->s0));
-    HIPCHK(hipEventSynchronize(h->ev_t1));
+    SYNC_S0(h);
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     if (elapsed_ms) *elapsed_ms = ms;
@@ -1608,7 +1889,7 @@ extern "C" int fibhip_time_end(fibhip_t h, float *elapsed_ms, int *launches)
     NEED(h);
     FLUSH(h);
     HIPCHK(hipEventRecord(h->ev_t1, h->s0));
-    HIPCHK(hipEventSynchronize(h->ev_t1));
+    SYNC_S0(h);
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     if (elapsed_ms) *elapsed_ms = ms;
@@ -1642,7 +1923,8 @@ extern "C" int fibhip_unit_op(int device, int op, int H, int W, const float *a, 
             if (hipMemcpy(dphi, phi, B, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(FIBHIP_EHIP, "unit_op: H2D failed"); break; }
             Geo g;
             g.H = g.Hg = H; g.W = W; g.pitch = W; g.row_off = 0; g.r0 = 0; g.r1 = H; g.rb0 = g.rb1 = g.ty_a = 0; g.tiles_x = g.ntiles = 0;
-            hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n);
+            hipLaunchKernelGGL(phase_prep_kernel, dim3(256), dim3(256), 0, 0, g, dphi, dph3, dph3 + n, dph3 + 2 * n, dph3 + 3 * n,
+                               (float *)nullptr, (float *)nullptr);
         }
         const float mdt = (float)(-dt);
         if (fast)
@@ -1993,6 +2275,7 @@ extern "C" int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_
 extern "C" int fibhip_ticks_per_launch(fibhip_t h)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
+    if (mt_variant(h)) return h->mt_max;
     return h->multi_max;
 }
 

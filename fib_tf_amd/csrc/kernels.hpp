@@ -61,6 +61,8 @@ struct PhaseTab {    // derived from ϕ once at set_phase (ionic.py:78-80)
     const float *dpx;   // ϕ[r,c+1] - ϕ[r,c-1]
     const float *q4;    // 4 * ϕ[r,c]
     const float *r4;    // RN(1 / q4): lets the division by 4ϕ run as a 3-instruction exact form
+    const float *pyr;   // RN(dpy * r4), RN(dpx * r4): all the fast policy needs of ϕ (its phase term is two FMAs on these
+    const float *pxr;   //   products; formed per launch until round 3, now once at set_phase: 8 B per cell instead of 16)
     const float *phi;   // ϕ itself: one-sub-step launches stage a ϕ tile in LDS and difference it on the fly
                         // (4 B per cell of traffic instead of 16; the K-fused kernels read the prepared arrays
                         // once per K sub-steps and keep them in registers)
@@ -130,6 +132,38 @@ static FIB_DEV float add_phase(float lap, float N, float S, float Wv, float E, f
     else
         return lap + phase_term<P>(N, S, Wv, E, dpy, dpx, q4, r4);
 }
+
+// What a thread of a K-fused kernel keeps of ϕ per cell, by arithmetic policy.  Exact: the four prepared arrays (the
+// quotient by 4ϕ is the correctly rounded one).  Fast: the two products dpy*r4, dpx*r4 — prepared by phase_prep_kernel
+// with the same single rounding the kernels used to apply per launch, so results are bit-identical to the four-array form.
+template <class P>
+struct PhaseCoef {
+    float dpy, dpx, q4, r4;
+    FIB_DEV void load(const PhaseTab &ph, int op)
+    {
+        dpy = ph.dpy[op];
+        dpx = ph.dpx[op];
+        q4 = ph.q4[op];
+        r4 = ph.r4[op];
+    }
+    FIB_DEV float add(float lap, float N, float S, float Wv, float E) const
+    {
+        return add_phase<P>(lap, N, S, Wv, E, dpy, dpx, q4, r4);
+    }
+};
+template <>
+struct PhaseCoef<Fast> {
+    float ay, ax;
+    FIB_DEV void load(const PhaseTab &ph, int op)
+    {
+        ay = ph.pyr[op];
+        ax = ph.pxr[op];
+    }
+    FIB_DEV float add(float lap, float N, float S, float Wv, float E) const
+    {
+        return __builtin_fmaf(E - Wv, ax, __builtin_fmaf(S - N, ay, lap));
+    }
+};
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous run of tiles so
 // that the halos neighbouring tiles share are served by the same L2.  Speed only, never correctness.
@@ -215,7 +249,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
 
     // ---- per-cell registers -------------------------------------------------------------------
     float s[CPT][NV];
-    float pdy[CPT], pdx[CPT], pq4[CPT], pr4[CPT];
+    PhaseCoef<P> pc[CPT];
     int li[CPT], off[CPT];
     unsigned fl[CPT];
 #pragma unroll
@@ -231,13 +265,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
         off[j] = oy * g.pitch + ox;
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[j][v] = pt.in[v][off[j]];
-        if (PHASE && !PHI_TILE) {
-            const int op = oy * g.W + ox;                          // the phase arrays are always planar
-            pdy[j] = ph.dpy[op];
-            pdx[j] = ph.dpx[op];
-            pq4[j] = ph.q4[op];
-            pr4[j] = ph.r4[op];
-        }
+        if (PHASE && !PHI_TILE) pc[j].load(ph, oy * g.W + ox);    // (the phase arrays are always planar)
         const bool border = gyg == 0 || gyg == g.Hg - 1 || gx == 0 || gx == g.W - 1;
         unsigned f = 0;
         if (indom) {
@@ -278,7 +306,7 @@ tick_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int su
                         l = l + ((S - N) * dy + (E - Wv) * dx) / (4.0f * lphi[i]);
                     }
                 } else if (PHASE) {
-                    l = add_phase<P>(l, N, S, Wv, E, pdy[j], pdx[j], pq4[j], pr4[j]);      // ionic.py:58
+                    l = pc[j].add(l, N, S, Wv, E);                                         // ionic.py:58
                 }
                 M::template step<P, TwoPass<M>::first(MODE)>(s[j], C, l, kk, sub0 + st);
             }
@@ -373,21 +401,58 @@ __device__ unsigned long long fib_stamps[4096 * 16];
 //       skipped with scalar branches — the box shrinks in y as the sub-steps proceed;
 //     * the vertical border/ghost refresh is wave-uniform too; only the two edge columns need a
 //       per-lane predicate.
-template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
-__global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
-strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0)
+// ---- several ticks in ONE launch: what a tile needs from its neighbours between two ticks ---------------------------
+// A launch of `nticks` ticks keeps every workgroup resident on its tile: the tile's own cells stay in registers from
+// tick to tick, and only the K-deep rim of the compute box (which went stale during the tick) is re-read — from what
+// the up to eight neighbouring tiles published at the end of their tick.  No grid-wide barrier: a tile waits for its
+// neighbours only.
+//   * Payload: an exchange buffer of 16-byte cells [2 parities][NVAR/4][H*W] (the state arrays themselves are read at
+//     the first tick and written at the last one only).  Stores and loads are write-through / L1-bypassing (sc1): the
+//     vector L1 of a CU is never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other
+//     (MI355X_MICROARCH.md, "inter-workgroup visibility"); every wave drains its stores (s_waitcnt vmcnt(0)) before the
+//     workgroup's barrier, after which ONE lane raises the tile's epoch word.
+//   * Epoch words: one per tile, 256 bytes apart (words sharing a line serialise the pollers of a whole tile row on one
+//     memory channel: measured 5.5 us per tick boundary against 3.1, tools/ubench/handoff.hip); they count ticks over
+//     the life of the handle (epoch0 = their common value when the launch starts), so nothing is reset between launches.
+//   * Two parities: a tile overwrites parity p two ticks after it published there, and by then every neighbour has
+//     published the tick in between, for which it had to read p first.
+//   * Every wait is BOUNDED (s_memrealtime, MT_WAIT_TICKS of 10 ns): a tile that gives up raises err[0], which every
+//     waiting tile also polls, so the launch drains instead of hanging; the host reports the failure at its next
+//     synchronisation point.  The host only uses this kernel when all tiles can be resident at once (tiles <= CUs)
+//     and never runs two such launches of one process at the same time.
+struct MtArgs {
+    float *xb;            // exchange buffer
+    unsigned *epoch;      // one word per tile, MT_EPOCH_STRIDE words apart
+    unsigned *err;        // [0]: a tile gave up waiting
+    unsigned epoch0;      // value of every epoch word when the launch starts
+    int nticks;           // ticks this launch advances
+};
+constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
+constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
+
+typedef unsigned fib_v4u __attribute__((ext_vector_type(4)));
+typedef float fib_v4f __attribute__((ext_vector_type(4)));
+
+// strip_kernel<M,P,MODE,K,TX,TY,R,PHASE> / strip_mt_kernel<...> share this body (MT = several ticks per launch)
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE, bool MT>
+static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const PhaseTab &ph, const typename M::Consts &k, int sub0,
+                               const MtArgs &mt)
 {
     constexpr int NV = M::NVAR;
     constexpr int CX = TX + 2 * (K - 1), CY = TY + 2 * (K - 1);
     static_assert(CX <= 62 && K > 1, "strip_kernel: compute box must fit 62 lanes");
+    static_assert(!MT || (CX == 62 && NV % 4 == 0 && TX >= K && TY >= K),
+                  "multi-tick launches: 62-column box, 16-byte cells, the rim inside the eight neighbours");
     constexpr int NW = (CY + R - 1) / R;
     constexpr int LP = 64, LQ = NW * R + 2, NL = LP * LQ;
     constexpr unsigned WMASK = M::mask(MODE);
     __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
+    __shared__ int mt_abort;
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;
     FIB_STAMP(0);
+    if (MT && threadIdx.x == 0) mt_abort = 0;                       // (read after the first tick's barriers)
     auto &&kk = M::pinned(k);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -425,22 +490,19 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
     const bool col_border = gx == 0 || gx == g.W - 1;
     const bool store_col = lane_in && gx >= x0 && gx < x0 + TX;
     const bool wr = lane_in && !col_border;                         // this lane's cells are somebody's taps
-    float s[R][NV], pdy[R], pdx[R], pq4[R], pr4[R];
+    float s[R][NV];
+    PhaseCoef<P> pc[R];
     int off[R];
+    bool own[R];                                                    // the cells this thread stores: the tile proper
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = cy0 + c0 + r;
         const int oy = clampi(gy, 0, g.H - 1), ox = clampi(gx, 0, g.W - 1);
         off[r] = oy * g.pitch + ox;
+        own[r] = store_col && gy >= y0 && gy < min(y0 + TY, rend) && gy < g.H;
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
-        if (PHASE) {
-            const int op = oy * g.W + ox;                           // the phase arrays are always planar
-            pdy[r] = ph.dpy[op];
-            pdx[r] = ph.dpx[op];
-            pq4[r] = ph.q4[op];
-            pr4[r] = ph.r4[op];
-        }
+        if (PHASE) pc[r].load(ph, oy * g.W + ox);                   // (the phase arrays are always planar)
     }
     // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
     // the box reaches the domain edge on that side (no staleness enters through a real boundary)
@@ -475,6 +537,8 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
 #define FIB_STEP_UNROLL 2
 #endif
     constexpr int STEP_UNROLL = FIB_STEP_UNROLL;
+#pragma unroll 1
+    for (int tick = 0;; ++tick) {
 #pragma unroll STEP_UNROLL
     for (int st = 0; st < K; ++st) {
         float *B = lds[(st & 1) ^ 1];
@@ -490,9 +554,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
             for (int r = 0; r < R; ++r) {
                 float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
                                   win[r][2], win[r + 2][2], win[r + 1][1]);
-                if (PHASE)
-                    l = add_phase<P>(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r], pq4[r],
-                                     pr4[r]);
+                if (PHASE) l = pc[r].add(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2]);
                 lp[r] = l;
                 cc[r] = win[r + 1][1];
             }
@@ -510,9 +572,7 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
                 if (r >= ra && r < rb) {                            // scalar branch
                     float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
                                       win[r][2], win[r + 2][2], win[r + 1][1]);
-                    if (PHASE)
-                        l = add_phase<P>(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], pdy[r], pdx[r],
-                                         pq4[r], pr4[r]);
+                    if (PHASE) l = pc[r].add(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2]);
                     M::template step<P, MODE>(s[r], win[r + 1][1], l, kk, sub0 + st);
                 }
             }
@@ -553,18 +613,148 @@ strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int s
         }
         FIB_STAMP(3 + st);
     }
+    if (!MT || tick + 1 >= mt.nticks) break;
+
+    // ================= between two ticks of one launch =================
+    if constexpr (MT) {
+        constexpr int NC4 = NV / 4;
+        const unsigned plane16 = (unsigned)(g.H * g.W) * 16u;       // bytes of one [H*W] array of 16-byte cells
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(mt.xb, 0, (int)(2u * NC4 * plane16), 0x00020000);
+        const unsigned pbase = (unsigned)(tick & 1) * NC4 * plane16;
+        // ---- publish the tile: 16-byte cells, write-through -------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (own[r]) {
+#pragma unroll
+                for (int c = 0; c < NC4; ++c) {
+                    const fib_v4f v = {s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fib_v4u, v), rs, (int)(pbase + c * plane16 + (unsigned)off[r] * 16u), 0, 16);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave, before the barrier
+        __syncthreads();
+        const unsigned want = mt.epoch0 + (unsigned)tick + 1u;
+        if (threadIdx.x == 0)
+            __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- wait for the eight neighbours (bounded) ---------------------------------------------------------
+        if (wave == 0) {
+            const int tiles_y = g.ntiles / g.tiles_x;
+            const int d = lane < 4 ? lane : lane + 1;               // 0..8 without the centre
+            const int ny = by + d / 3 - 1, nx = bx + d % 3 - 1;
+            const bool need = lane < 8 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < g.tiles_x;
+            // lane 8 watches the give-up word instead
+            const unsigned *f = lane == 8 ? mt.err : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE;
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + MT_WAIT_TICKS;
+            for (;;) {
+                const unsigned e = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool gave_up = __builtin_amdgcn_ballot_w64(lane == 8 && e != 0u) != 0ull;
+                // (epochs are compared as differences: they may wrap)
+                const bool ready = __builtin_amdgcn_ballot_w64(need && (int)(e - want) < 0) == 0ull;
+                if (ready && !gave_up) break;
+                if (gave_up || __builtin_amdgcn_s_memrealtime() > t_end) {
+                    if (lane == 0) {
+                        __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mt_abort = 1;
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (mt_abort) return;                                       // whole workgroup: the results of this launch are void
+        // ---- the rim of the compute box, from what the neighbours published ------------------------------
+        // (every load of handed-over bytes is an sc1 load; a thread outside the box or the grid reads a clamped
+        // address like the prologue does: its values are never used)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!own[r]) {
+#pragma unroll
+                for (int c = 0; c < NC4; ++c) {
+                    // (whole-vector bit cast: __builtin_bit_cast of ONE element of a vector reads element 0 for every index
+                    // with this compiler)
+                    const fib_v4f v = __builtin_bit_cast(
+                        fib_v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(pbase + c * plane16 + (unsigned)off[r] * 16u), 0, 16));
+                    s[r][4 * c] = v.x;
+                    s[r][4 * c + 1] = v.y;
+                    s[r][4 * c + 2] = v.z;
+                    s[r][4 * c + 3] = v.w;
+                }
+            }
+        }
+        // the potential of the two ring rows around the box (tapped by the first sub-step only), where they are
+        // interior rows of the grid: loaded by the first / last wave
+        const int gtop = cy0 - 1 + g.row_off, gbot = cy0 + CY + g.row_off;
+        const int cxx = clampi(gx, 0, g.W - 1);
+        float ring = 0.0f;
+        const bool ring_top = wave == 0 && gtop >= 1 && gtop <= g.Hg - 2;
+        const bool ring_bot = wave == NW - 1 && gbot >= 1 && gbot <= g.Hg - 2;
+        if (ring_top)
+            ring = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(pbase + (unsigned)((cy0 - 1) * g.W + cxx) * 16u), 0, 16));
+        if (ring_bot)
+            ring = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(pbase + (unsigned)((cy0 + CY) * g.W + cxx) * 16u), 0, 16));
+        // ---- the whole box's potential into the tile, as after a sub-step — plus the ring (columns 0 and 63 of the
+        // tile, rows 0 and CY+1), which the sub-steps never write
+        float *B0 = lds[0];
+        const int wib = (gx >= 1 && gx <= g.W - 2) ? (c0 + 1) * LP + lane : NL + 2 * LP + lane;
+        {
+            const unsigned live = ra_fix < rb_fix ? ((1u << rb_fix) - 1u) & ~((1u << ra_fix) - 1u) : 0u;
+            const unsigned m = live & pub;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((m >> r) & 1u) B0[wib + r * LP] = s[r][0];
+            if (top_r >= 0 || bot_r >= 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r == top_r && ((live >> r) & 1u)) {
+                        B0[wib + (r - 1) * LP] = s[r][0];
+                        if (c0 + r >= 1) B0[wib + (r - 2) * LP] = s[r][0];
+                    }
+                    if (r == bot_r && ((live >> r) & 1u)) {
+                        B0[wib + (r + 1) * LP] = s[r][0];
+                        if (c0 + r + 1 < LQ - 2) B0[wib + (r + 2) * LP] = s[r][0];
+                    }
+                }
+            }
+            if (ring_top) B0[(gx >= 1 && gx <= g.W - 2) ? lane : NL + 2 * LP + lane] = ring;
+            if (ring_bot) B0[(gx >= 1 && gx <= g.W - 2) ? (CY + 1) * LP + lane : NL + 2 * LP + lane] = ring;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R + 2; ++q) {
+            win[q][0] = B0[aW + q * LP];
+            win[q][1] = B0[aC + q * LP];
+            win[q][2] = B0[aE + q * LP];
+        }
+    }
+    }
 
     // ---- write back ---------------------------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int gy = cy0 + wave * R + r;
-        if (store_col && gy >= y0 && gy < min(y0 + TY, rend) && gy < g.H) {
+        if (own[r]) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if ((WMASK >> v) & 1u) pt.out[v][off[r]] = s[r][v];
         }
     }
     FIB_STAMP(14);
+}
+
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+__global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
+strip_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0)
+{
+    strip_body<M, P, MODE, K, TX, TY, R, PHASE, false>(g, pt, ph, k, sub0, MtArgs{});
+}
+
+// the same tile program advancing `mt.nticks` ticks of K sub-steps each (K = the tick's sub-steps) in one launch
+template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
+__global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
+strip_mt_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0, MtArgs mt)
+{
+    strip_body<M, P, MODE, K, TX, TY, R, PHASE, true>(g, pt, ph, k, sub0, mt);
 }
 
 // ---- wavefront-level neighbour access (gfx9 DPP wavefront shifts) -----------------------------------
@@ -590,7 +780,7 @@ static FIB_DEV float lane_get(float v, int lane)     // lane: wave-uniform
 // stencil9 / phase_term: NW + SW is the neighbouring lane's own N + S (the same float32 addition of the same
 // two numbers), so `lane_west(N + S)` is bit-identical to forming it here.
 template <class P, bool PHASE>
-static FIB_DEV float stencil9_lanes(float N, float S, float C, float dpy, float dpx, float q4, float r4)
+static FIB_DEV float stencil9_lanes(float N, float S, float C, const PhaseCoef<P> &pc)
 {
     const float ns = N + S;
     const float Wv = lane_west(C), E = lane_east(C);
@@ -601,7 +791,7 @@ static FIB_DEV float stencil9_lanes(float N, float S, float C, float dpy, float 
             __builtin_fmaf(-6.0f, C, Wv + E);
     else
         r = (l1 + 0.5f * d) - 6.0f * C;
-    if (PHASE) r = add_phase<P>(r, N, S, Wv, E, dpy, dpx, q4, r4);
+    if (PHASE) r = pc.add(r, N, S, Wv, E);
     return r;
 }
 
@@ -646,7 +836,8 @@ static FIB_DEV void rows_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Pha
     FIB_STAMP(0);
 
     // ---- prologue: every global load is issued before anything waits -------------------------------------
-    float s[R][NV], e[R], pdy[R], pdx[R], pq4[R], pr4[R];
+    float s[R][NV], e[R];
+    PhaseCoef<P> pc[R];
     int off[R];
     auto brow = [&](int grow) {                                     // global row -> local row through the boundary clamp
         return clampi(clampi(grow, 1, g.Hg - 2) - g.row_off, 0, g.H - 1);
@@ -659,13 +850,7 @@ static FIB_DEV void rows_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Pha
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
         if (EDGE) e[r] = pt.in[0][(size_t)brow(g0 + r) * g.pitch + bxx];
-        if (PHASE) {
-            const int op = oy * g.W + ox;                           // the phase arrays are always planar
-            pdy[r] = ph.dpy[op];
-            pdx[r] = ph.dpx[op];
-            pq4[r] = ph.q4[op];
-            pr4[r] = ph.r4[op];
-        }
+        if (PHASE) pc[r].load(ph, oy * g.W + ox);                   // (the phase arrays are always planar)
     }
     float eN = pt.in[0][(size_t)brow(g0 - 1) * g.pitch + bxx];      // the rows above / below the strip
     float eS = pt.in[0][(size_t)brow(glast + 1) * g.pitch + bxx];
@@ -695,8 +880,7 @@ static FIB_DEV void rows_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Pha
             float lp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pdy[r], pdx[r],
-                                                 pq4[r], pr4[r]);
+                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pc[r]);
             if constexpr (M::HAS_VEC) {
                 M::template stepN<P, MODE, R>(s, e, lp, kk, sub0 + st);
             } else {
@@ -708,8 +892,7 @@ static FIB_DEV void rows_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Pha
             float lp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pdy[r], pdx[r],
-                                                 pq4[r], pr4[r]);
+                lp[r] = stencil9_lanes<P, PHASE>(r == 0 ? eN : e[r - 1], r == R - 1 ? eS : e[r + 1], e[r], pc[r]);
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (r >= ra && r < rb) M::template step<P, MODE>(s[r], e[r], lp[r], kk, sub0 + st);   // scalar branch
@@ -852,8 +1035,8 @@ __global__ void unit_op_kernel(int op, int H, int W, const float *a, const float
     }
 }
 
-// ϕ -> (dpy, dpx, q4), REFLECT-padded in GLOBAL coordinates (ionic.py:75-80)
-__global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dpx, float *q4, float *r4)
+// ϕ -> (dpy, dpx, q4, r4) and the fast policy's two products, REFLECT-padded in GLOBAL coordinates (ionic.py:75-80)
+__global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dpx, float *q4, float *r4, float *pyr, float *pxr)
 {
     const int n = g.H * g.W;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
@@ -869,6 +1052,10 @@ __global__ void phase_prep_kernel(Geo g, const float *phi, float *dpy, float *dp
         dpx[e] = phi[y * g.W + xe] - phi[y * g.W + xw];
         q4[e] = 4.0f * phi[e];
         r4[e] = 1.0f / q4[e];                       // IEEE division: correctly rounded reciprocal
+        if (pyr) {                                  // one rounding each (-ffp-contract=off), as add_phase<Fast> forms them
+            pyr[e] = dpy[e] * r4[e];
+            pxr[e] = dpx[e] * r4[e];
+        }
     }
 }
 
@@ -906,7 +1093,6 @@ __global__ void court_inter_kernel(int n, const float *__restrict__ V, float *__
 // bench.py prints next to the roofline peak.  (tools/ubench/copybw.hip -> profiles/r02_copy_bandwidth_shapes.txt: this
 // shape reaches the 6.3 TB/s the microarch guide quotes; grid-stride loops with non-temporal accesses stay at 4.6-5.7,
 // reads alone run at 7.0, writes alone at 4.4 TB/s)
-typedef float fib_v4f __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) copy_kernel(const fib_v4f *__restrict__ src, fib_v4f *__restrict__ dst, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -512,6 +512,218 @@ def test_fenton_fusion_depths_bit_identical(gpu_lib, monkeypatch, policy):
         assert np.array_equal(v, base), 'variant %s differs from one-step-per-launch' % k
 
 
+
+# --------------------------------------------------------------------------------------------
+# several ticks per launch (strip_mt_kernel): a grid whose tiles are all resident at once runs consecutive Fenton
+# ticks as ONE launch whose tiles hand the rim of their compute box to each other between two ticks
+# --------------------------------------------------------------------------------------------
+def _fenton_state(H, W, seed):
+    rng = np.random.default_rng(seed)
+    init = np.empty((4, H, W), np.float32)
+    init[0] = rng.uniform(-0.02, 1.0, (H, W))
+    init[1] = rng.uniform(0, 1, (H, W))
+    init[2] = rng.uniform(0, 1, (H, W))
+    init[3] = rng.uniform(0, 1, (H, W))
+    phi = rng.uniform(0.3, 1.0, (H, W)).astype(np.float32)
+    return init, phi
+
+
+def _fenton_play(monkeypatch, mt, H, W, policy, phase, steps, variant=None):
+    from fib_tf_amd import _lib
+    if mt:
+        monkeypatch.delenv('FIBHIP_MT', raising=False)
+    else:
+        monkeypatch.setenv('FIBHIP_MT', '0')
+    if variant:
+        monkeypatch.setenv('FIBHIP_VARIANT', variant)
+    else:
+        monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+    init, phi = _fenton_state(H, W, 7 * H + W)
+    st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST if policy == 'fast' else 0)
+    if phase:
+        st.set_phase(phi)
+    st.set_state(-1, init)
+    out = []
+    for n in steps:
+        if n == 'pace':
+            st.pace(H // 4, H // 4 + 5, W // 3, W // 3 + 6, 1.0, 0.0)
+        elif n == 'get':
+            out.append(st.get_state(0).copy())
+        elif isinstance(n, tuple):                            # n single-tick calls, as run() issues them
+            for _ in range(n[0]):
+                st.step(1)
+        else:
+            st.step(n)
+    out.append(st.get_state(-1))
+    tpl, launches = st.ticks_per_launch(), None
+    st.close()
+    return out, tpl
+
+
+@pytest.mark.parametrize('policy', POLICIES)
+@pytest.mark.parametrize('phase', [True, False])
+@pytest.mark.parametrize('H,W,variant', [(45, 70, '10,44,25,-3'), (64, 64, '10,44,28,-3'), (200, 300, '10,44,25,-3'), (130, 89, '10,44,32,-4'),
+                                         (512, 512, None), (3, 5, '10,44,25,-3'), (26, 45, '10,44,25,-3')])
+def test_fenton_multi_tick_launches_bit_identical(gpu_lib, monkeypatch, policy, phase, H, W, variant):
+    """T ticks in one launch (tiles exchanging their rims through the 16-byte-cell buffer, neighbour-only waits) against
+    one launch per tick (FIBHIP_MT=0): the same arithmetic per cell, so not a bit may differ — with calls of many ticks
+    (several full launches + a remainder), single-tick calls (launches of 1, 2, 4, ... ticks), a pace and a read-back in
+    between.  512x512 is the benchmark's own tiling: 252 workgroups, one per compute unit."""
+    steps = [1, 3, 'pace', 37, 'get', (21,), 'pace', 2, (5,), 'get', 70]
+    a, tpl = _fenton_play(monkeypatch, True, H, W, policy, phase, steps, variant)
+    b, _ = _fenton_play(monkeypatch, False, H, W, policy, phase, steps, variant)
+    if variant or policy == 'fast':      # (the rounding-faithful policy runs 512x512 as two launches of 5 sub-steps: one per tick)
+        assert tpl > 1, 'the multi-tick path was not taken'
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.isfinite(x).all()
+        assert np.array_equal(x, y), 'observation %d differs (max |d| %.3g)' % (i, float(np.abs(x - y).max()))
+
+
+def test_fenton_multi_tick_launch_count(gpu_lib, monkeypatch):
+    """twenty single-tick calls and a sync: launches of 1, 2, 4, 8 ticks and the remaining 5; one call of 70 ticks: 32 + 32
+    + 6 (the last one at the sync)"""
+    from fib_tf_amd import _lib
+    monkeypatch.delenv('FIBHIP_MT', raising=False)
+    monkeypatch.delenv('FIBHIP_MT_MAX', raising=False)
+    monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+    init, phi = _fenton_state(96, 100, 5)
+    st = _lib.Stepper(_lib.FENTON4V, 96, 100, 0.1, 1.3, flags=_lib.FAST)
+    st.set_state(-1, init)
+    st.step(1)
+    st.sync()
+    st.time_begin()
+    for _ in range(20):
+        st.step(1)
+    ms, launches = st.time_end()
+    assert launches == 5, launches
+    st.time_begin()
+    st.step(70)
+    ms, launches = st.time_end()
+    assert launches == 3, launches
+    st.close()
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_fenton_deferred_ticks_random_call_sequences(gpu_lib, monkeypatch, seed):
+    """fibhip_step is an enqueue here too: whatever the caller does between ticks must see and leave exactly what one
+    launch per tick leaves (random call sequences, compared observation by observation with FIBHIP_MT=0)"""
+    from fib_tf_amd import _lib
+    H, W = 83, 120
+    init, phi = _fenton_state(H, W, 100 + seed)
+
+    def play(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        rng = np.random.default_rng(seed)
+        st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        seen = []
+        for _ in range(150):
+            op = rng.choice(['step1', 'step1', 'step1', 'step1', 'stepn', 'pace', 'probe', 'get1', 'getall', 'set1', 'sync', 'timed',
+                             'phase'])
+            if op == 'step1':
+                st.step(1)
+            elif op == 'stepn':
+                st.step(int(rng.integers(0, 45)))
+            elif op == 'pace':
+                r0, c0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+                st.pace(r0, r0 + 4, c0, c0 + 4, 1.0, 0.0)
+            elif op == 'probe':
+                seen.append(np.float32(st.probe(int(rng.integers(0, 4)), int(rng.integers(0, H)), int(rng.integers(0, W)))))
+            elif op == 'get1':
+                seen.append(st.get_state(int(rng.integers(0, 4))).copy())
+            elif op == 'getall':
+                seen.append(st.get_state(-1))
+            elif op == 'set1':
+                v = int(rng.integers(1, 4))
+                st.set_state(v, (st.get_state(v) * np.float32(0.999)).astype(np.float32))
+            elif op == 'sync':
+                st.sync()
+            elif op == 'phase':
+                st.set_phase(phi if rng.integers(0, 2) else None)
+            else:
+                st.time_begin()
+                st.step(int(rng.integers(1, 6)))
+                st.time_end()
+        seen.append(st.get_state(-1))
+        st.close()
+        return seen
+
+    a, b = play(True), play(False)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), 'observation %d differs' % i
+
+
+def test_two_handles_multi_tick_side_by_side(gpu_lib, monkeypatch):
+    """two handles on their own streams, each wanting every compute unit for its resident tiles: the library orders their
+    multi-tick launches one behind the other (two half-resident grids would wait for each other)"""
+    from fib_tf_amd import _lib
+    monkeypatch.delenv('FIBHIP_MT', raising=False)
+    monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+    H = W = 512
+    init, phi = _fenton_state(H, W, 3)
+    hs = [_lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST) for _ in range(2)]
+    for st in hs:
+        st.set_phase(phi)
+        st.set_state(-1, init)
+    for _ in range(6):
+        for st in hs:
+            st.step(40)
+    a, b = [st.get_state(-1) for st in hs]
+    for st in hs:
+        st.close()
+    assert np.isfinite(a).all()
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('policy', POLICIES)
+@pytest.mark.parametrize('cheby,skip', [(True, False), (False, False), (True, True), (False, True)])
+@pytest.mark.parametrize('H,W,variant', [(70, 130, '5,54,21,-2'), (45, 70, '5,54,27,-3'), (512, 512, None)])
+def test_br_multi_tick_launches_bit_identical(gpu_lib, monkeypatch, policy, cheby, skip, H, W, variant):
+    """Beeler-Reuter ticks (5 sub-steps, eight arrays = two 16-byte cells per grid cell) several per launch against one
+    launch per tick: bit-identical, for both gate forms, with the `skip` multirate schedule (the sub-step index restarts
+    with every tick inside the launch), on the stock library (forced tile shape) and on the specialised build (512x512)"""
+    from fib_tf_amd.br import BeelerReuter
+    if H == 512 and (skip or not cheby):
+        pytest.skip('the full-size case runs once per policy')
+
+    def play(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        if variant:
+            monkeypatch.setenv('FIBHIP_VARIANT', variant)
+        else:
+            monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+        m = BeelerReuter(cfg(H, W, 0.809, policy, cheby=cheby, skip=skip))
+        m.add_hole_to_phase_field(H * 0.3, W * 0.4, min(H, W) * 0.12)
+        m.define()
+        st = m._stepper
+        out = []
+        for n in (1, 2, 7, 'pace', 40, 'get', 3, 33):
+            if n == 'pace':
+                st.pace(0, H // 2, 0, W // 2, 10.0, -100.0)
+            elif n == 'get':
+                out.append(st.get_state(0).copy())
+            else:
+                st.step(n)
+        out.append(st.get_state(-1))
+        tpl = st.ticks_per_launch()
+        st.close()
+        return out, tpl
+
+    (a, tpl), (b, _) = play(True), play(False)
+    if variant:
+        assert tpl > 1, 'the multi-tick path was not taken'
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.isfinite(x).all()
+        assert np.array_equal(x, y), 'observation %d differs (max |d| %.3g)' % (i, float(np.abs(x - y).max()))
+
 @pytest.mark.parametrize('policy', POLICIES)
 def test_fenton_ragged_nophase(gpu_lib, golden, policy):
     from fib_tf_amd.fenton import Fenton4v
