@@ -42,7 +42,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # rocprofv3 --pmc passes of this command, condensed by tools/prof_summary.py (PMC cannot run inside the bench)
-COUNTERS_JSON = [os.path.join(ROOT, 'profiles', 'counters_r02.json'), os.path.join(ROOT, 'profiles', 'traffic_r01.json')]
+COUNTERS_JSON = [os.path.join(ROOT, 'profiles', 'counters_r03.json'), os.path.join(ROOT, 'profiles', 'counters_r02.json'),
+                 os.path.join(ROOT, 'profiles', 'traffic_r01.json')]
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32; max shader clock (MI355X_MICROARCH.md, chip-level parameters)
 CYC_VALU, CYC_TRANS = 2.0, 8.0   # issue cycles of a wave64 VALU / transcendental instruction on one SIMD (same guide)
@@ -180,41 +181,53 @@ def counters_for(key):
     return {}
 
 
-def roofline_extras(roof, key, us_per_launch, own_time=False):
+def roofline_extras(roof, key, us_per_launch, own_time=False, tile=None, ticks_per_launch=1):
     """traffic / issue ceiling / cache hit rates of the dominant kernel from the committed counter passes;
     own_time: the timed launches are a mix of kernels (Courtemanche), so the counters of the dominant one are set against
-    its own duration in the same profile instead of the mean launch of the mix"""
+    its own duration in the same profile instead of the mean launch of the mix.
+    A record made of multi-tick launches holds PER-TICK figures (`per: tick`); they are scaled to this run's ticks per
+    launch.  A record whose kernel has another tile shape than this run's plan (first-tick measurement picks per box) is
+    not mixed in: it is named, flagged `stale`, and no figure is derived from it."""
     rec = counters_for(key)
+    roof['counters_key'] = key
+    if rec and tile is not None and rec.get('tile') and list(rec['tile']) != list(tile):
+        roof['counters_stale'] = ('%s [%s] was recorded on tile %s, this run chose %s: no traffic / issue / cache figures'
+                                  % (rec.get('source'), key, 'x'.join(map(str, rec['tile'])), 'x'.join(map(str, tile))))
+        return roof
+    scale = float(ticks_per_launch) if rec.get('per') == 'tick' else 1.0
     if own_time and rec.get('us_per_launch_under_trace'):
         us_per_launch = rec['us_per_launch_under_trace']
-    roof['counters_key'] = key
-    roof['traffic'] = rec.get('hbm_bytes_per_launch_corrected')
+    t = rec.get('hbm_bytes_per_launch_corrected')
+    roof['traffic'] = None if t is None else t * scale
     valu, trans = rec.get('SQ_INSTS_VALU'), rec.get('SQ_INSTS_VALU_TRANS_F32')
     if valu is not None:
         # wave-instructions per launch over all waves; a SIMD issues a wave64 VALU instruction in 2 cycles and a
         # transcendental in 8: the time the chip's 1024 SIMDs need just to ISSUE them, against the launch time
-        t = trans or 0.0
+        valu *= scale
+        t = (trans or 0.0) * scale
         cycles = ((valu - t) * CYC_VALU + t * CYC_TRANS) / N_SIMD
         us = cycles / (CLOCK_GHZ * 1e3)
         roof['issue'] = {'bound': 'valu-issue', 'valu_wave_instr_per_launch': round(valu), 'trans_wave_instr_per_launch':
-                         None if trans is None else round(trans), 'salu_wave_instr_per_launch':
-                         None if rec.get('SQ_INSTS_SALU') is None else round(rec['SQ_INSTS_SALU']),
+                         None if trans is None else round(t), 'salu_wave_instr_per_launch':
+                         None if rec.get('SQ_INSTS_SALU') is None else round(rec['SQ_INSTS_SALU'] * scale),
                          'cycles_per_valu': CYC_VALU, 'cycles_per_trans': CYC_TRANS, 'simds': N_SIMD, 'clock_ghz': CLOCK_GHZ,
                          'issue_us_per_launch': round(us, 3), 'frac': round(us / us_per_launch, 4),
                          'note': 'fraction of the launch the SIMDs spend issuing vector instructions; this, not HBM, is '
                                  'the ceiling once K sub-steps are fused (frac of the HBM figure can then exceed 1)'}
     hit, miss = rec.get('TCC_HIT_sum'), rec.get('TCC_MISS_sum')
     if hit is not None and miss is not None and hit + miss > 0:
-        roof['cache'] = {'l2_hit_rate': round(hit / (hit + miss), 4), 'TCC_HIT_sum': round(hit), 'TCC_MISS_sum': round(miss)}
+        roof['cache'] = {'l2_hit_rate': round(hit / (hit + miss), 4), 'TCC_HIT_sum': round(hit * scale), 'TCC_MISS_sum': round(miss * scale)}
         for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_WRREQ_sum', 'TCC_EA0_WRREQ_DRAM_sum'):
             if rec.get(k) is not None:
-                roof['cache'][k] = round(rec[k])
+                roof['cache'][k] = round(rec[k] * scale)
         roof['cache']['note'] = ('TCC_HIT/MISS: the XCDs\' L2s.  TCC_EA0_*REQ: 64-B requests leaving the L2s towards the '
                                  'fabric; on gfx950 the _DRAM variants count the same requests (Infinity-Cache hits are not '
                                  'told apart, MI355X_MICROARCH.md "HBM"), so no Infinity-Cache hit rate can be derived; the '
                                  'working set of this launch is far below its 256 MiB')
     if rec:
-        roof['counters_source'] = '%s [%s], kernel %s' % (rec.get('source'), key, rec.get('kernel', '?'))
+        roof['counters_source'] = '%s [%s], kernel %s%s' % (rec.get('source'), key, rec.get('kernel', '?'),
+                                                            ' (recorded per tick, scaled to %d ticks per launch)' % ticks_per_launch
+                                                            if scale != 1.0 else '')
     return roof
 
 
@@ -262,8 +275,9 @@ def kernel_key(args, exact, H, W, fused, shard=False, ticks=1):
                                    ticks if ticks > 1 else fused, '/shard' if shard else '')
 
 
-def measure_single(args, exact, with_extras):
+def measure_single(args, exact, with_extras, snapshots=None):
     """one model on device 0: (value, ms_per_tick, roofline dict, walls, snapshots value, model)"""
+    snapshots = with_extras if snapshots is None else snapshots
     m, (loc, amp, s2_ms) = make_model(args, device=0, exact=exact)
     m.define()
     m.add_pace_op('s2', loc, amp)
@@ -282,29 +296,47 @@ def measure_single(args, exact, with_extras):
     cells = m.height * m.width
     value = cells * args.steps * spt / wall / 1e6
 
-    # dominant kernel: HIP events on the kernel's own stream around the SAME tick mix (for Courtemanche that
-    # includes every 10th tick's fused fast+slow launch), back-to-back launches
+    # dominant kernel: HIP events on the kernel's own stream, back-to-back launches.  Courtemanche: around the SAME tick
+    # mix as above (every 10th tick's fused fast+slow launch included).  Multi-tick launches (Fenton / Beeler-Reuter on a
+    # grid whose tiles are all resident at once): whole launches of `tpl` ticks, handed over in one call.
+    tpl = st.ticks_per_launch()
+    multi = tpl > 1 and not court
     nt = max(50, min(args.steps, 500))
     if court:
         nt = (nt + 9) // 10 * 10                      # whole fast/slow periods
     st.sync()
-    st.time_begin()
-    advance(nt)
-    ms, launches = st.time_end()
+    if multi:
+        nt = max(4, min(16, args.steps // tpl)) * tpl
+        st.time_begin()
+        st.step(nt)
+        ms, launches = st.time_end()
+    else:
+        st.time_begin()
+        advance(nt)
+        ms, launches = st.time_end()
     us_per_launch = ms * 1000.0 / max(1, launches)
     abytes = ALGO_BYTES[args.model] + (4 if m.phase is not None else 0)
     per_launch_bytes = abytes * cells * spt * nt / max(1, launches)      # mean over the launches of the mix
     achieved = per_launch_bytes / (us_per_launch * 1e-6) / 1e9
     name = 'strip_kernel' if fused > 1 and args.model in ('fenton', 'br') else 'tick_kernel'
-    tpl = st.ticks_per_launch()
+    if multi:
+        kname = 'strip_mt_kernel<%s, K=%d, %d ticks per launch>' % (args.model, fused, nt // max(1, launches))
+    elif tpl > 1:
+        kname = 'strip_kernel<%s on aggregates, %d ticks per launch>' % (args.model, tpl)
+    else:
+        kname = '%s<%s, K=%d>' % (name, args.model, fused)
     roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-            'kernel': ('strip_kernel<%s on aggregates, %d ticks per launch>' % (args.model, tpl)) if tpl > 1 else
-                      '%s<%s, K=%d>' % (name, args.model, fused), 'us_per_launch': round(us_per_launch, 3),
-            'launches_timed': launches, 'ticks_timed': nt,
+            'kernel': kname, 'us_per_launch': round(us_per_launch, 3),
+            'launches_timed': launches, 'ticks_timed': nt, 'ticks_per_launch': round(nt / max(1, launches), 2),
+            'us_per_tick': round(ms * 1000.0 / nt, 3),
             'algorithmic_bytes_per_launch': int(per_launch_bytes),
             'note': 'working set is LDS/L2/Infinity-Cache resident; algorithmic bytes are what a '
                     'one-step-per-pass implementation must move, K fused sub-steps move them once'}
+    if multi:
+        roof['note'] += ('; one launch advances %d ticks: a tile keeps its cells in registers and re-reads the rim of its '
+                         'compute box from its eight neighbours between two ticks (the state arrays are read at the first '
+                         'and written at the last tick of a launch)' % (nt // max(1, launches)))
     if court:
         roof['note'] += ('; Courtemanche: the timed mix is 9 fast ticks (%.0f B/cell) + 1 fused fast+slow tick '
                          '(%.0f B/cell) per 10, bytes and time both of the mix' % (COURT_FAST_BYTES + 4, COURT_SLOW_BYTES + 4))
@@ -314,11 +346,53 @@ def measure_single(args, exact, with_extras):
                              'fewer bytes than the algorithmic figure, which is why frac can exceed 1 — see `issue`' % tpl)
     snaps = None
     if with_extras:
-        roofline_extras(roof, kernel_key(args, exact, m.height, m.width, fused, ticks=tpl), us_per_launch, own_time=court)
+        tw, th, tr = st.plan_tile()
+        roofline_extras(roof, kernel_key(args, exact, m.height, m.width, fused, ticks=tpl), us_per_launch, own_time=court,
+                        tile=(tw, th, tr), ticks_per_launch=max(1, nt // max(1, launches)) if multi else 1)
+    if snapshots:
         m.image()                                     # set-up: the pinned staging buffer of the read-backs
         ws = timed_regions(advance, st.sync, args.steps, 1, snap=True)
         snaps = cells * args.steps * spt / ws[0] / 1e6
     return value, wall * 1000.0 / args.steps, roof, walls, snaps, m
+
+
+def plan_text(st):
+    fused, per_tick = st.launch_plan()
+    t = st.plan_tile()
+    tpl = st.ticks_per_launch()
+    return '%d sub-steps per launch x %d launch(es) per tick%s, tile %dx%d (%s)' % (
+        fused, per_tick, (', up to %d ticks per launch' % tpl) if tpl > 1 else '', t[0], t[1],
+        ('%d rows per wave' % t[2]) if t[2] > 0 else ('%d threads' % -t[2]))
+
+
+# the other single-GPU configurations of BASELINE.json, timed in the same run with a bounded number of ticks
+CONFIG_LEGS = [
+    ('configs[2] Beeler-Reuter 8-var 512x512, cheby=True', 'br', 512, 600, 200),
+    ('configs[4] Courtemanche 21-var 1024x1024, slow fired every 10th tick as court.py:612-617 does', 'court', 1024, 600, 200),
+    ('configs[3] grid on ONE device: Fenton 4v 4096x4096', 'fenton', 4096, 100, 30),
+]
+
+
+def config_legs(args):
+    import copy
+    out = []
+    for label, model, size, steps, setup in CONFIG_LEGS:
+        a = copy.copy(args)
+        a.model, a.size, a.steps, a.setup, a.warmup, a.repeats, a.exact = model, size, steps, setup, 20, 3, False
+        try:
+            value, ms_tick, roof, walls, _, m = measure_single(a, False, True, snapshots=False)
+            st = m._stepper
+            leg = {'config': label, 'value': round(value, 1), 'unit': 'Mcell-steps/s', 'ms_per_step': round(ms_tick, 6),
+                   'steps': steps, 'timing': 'median of 3 regions of %d ticks' % steps, 'plan': plan_text(st),
+                   'roofline': {k: roof.get(k) for k in ('frac', 'achieved', 'us_per_launch', 'us_per_tick', 'ticks_per_launch', 'kernel',
+                                                         'traffic', 'counters_key', 'counters_source', 'counters_stale')
+                                if roof.get(k) is not None},
+                   'issue_frac': roof.get('issue', {}).get('frac')}
+            st.close()
+        except Exception as e:                            # a leg never costs the headline line
+            leg = {'config': label, 'error': '%s: %s' % (type(e).__name__, e)}
+        out.append(leg)
+    return out
 
 
 def bench_single(args):
@@ -330,13 +404,13 @@ def bench_single(args):
         'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d' % (
             {'fenton': '4v', 'br': 'BR', 'court': 'Courtemanche'}[args.model], m.height, m.width),
         'value': round(value, 1), 'unit': 'Mcell-steps/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_tick, 6), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(ms_tick, 6), 'higher_is_better': True, 'scaling': 'none (one device, nothing is scaled)',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %dx%d, dt=0.1 ms, phase-field hole, S1 + S2 pacing (BASELINE configs[%d]); '
                                '1 step = 1 run() tick = %d sub-steps' % (
                                    args.model, m.height, m.width, {'fenton': 1, 'br': 2, 'court': 4}[args.model], spt),
                    'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
-                   'ticks_per_launch': st.ticks_per_launch(),
+                   'ticks_per_launch': st.ticks_per_launch(), 'launch_stats': st.launch_stats(),
                    'tile': '%dx%d cells, %s (chosen by measurement on the first tick)' % (
                        (lambda t: (t[0], t[1], ('%d rows per wave' % t[2]) if t[2] > 0 else ('%d threads' % -t[2])))(st.plan_tile())),
                    'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
@@ -350,19 +424,24 @@ def bench_single(args):
     }
     try:                                              # achievable-bandwidth yardstick, measured in this very run
         from fib_tf_amd import _lib
-        out['roofline']['copy_bandwidth_measured'] = round(_lib.copy_bandwidth(1 << 30, 5, m.device, library=m._library), 1)
+        out['roofline']['copy_bandwidth_measured'] = round(_lib.copy_bandwidth(1 << 30, 5, m.device), 1)   # (from the stock library)
     except Exception as e:                            # never lose the result line over the yardstick
         out['roofline']['copy_bandwidth_measured'] = None
         print('copy bandwidth not measured: %s' % e, file=sys.stderr)
     if not args.exact and not args.no_exact_leg:      # the rounding-faithful policy, timed the same way
         st.close()
-        ev, ems, eroof, ewalls, _, em = measure_single(args, True, False)
+        ev, ems, eroof, ewalls, _, em = measure_single(args, True, True, snapshots=False)
         ek, _ = em._stepper.launch_plan()
         out['exact'] = {'value': round(ev, 1), 'ms_per_step': round(ems, 6), 'arithmetic': 'exact (one float32 rounding '
                         'per reference op, no FMA contraction: the policy the bit-level parity claims hold for)',
                         'roofline_frac': eroof['frac'], 'us_per_launch': eroof['us_per_launch'],
-                        'fused_sub_steps_per_launch': ek}
+                        'fused_sub_steps_per_launch': ek, 'plan': plan_text(em._stepper),
+                        'traffic': eroof.get('traffic'), 'issue_frac': eroof.get('issue', {}).get('frac'),
+                        'counters_source': eroof.get('counters_source', eroof.get('counters_stale'))}
         em._stepper.close()
+    if args.model == 'fenton' and args.size == 512 and not args.exact and not args.no_config_legs:
+        st.close()
+        out['configs'] = config_legs(args)
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args)
     return out
@@ -380,9 +459,30 @@ def free_port():
 
 
 def visible_devices():
-    """HIP devices this process could open, WITHOUT opening one (the parent of the ranks must stay off the GPU)"""
-    import torch
-    return torch.cuda.device_count()
+    """GPUs this process could open, WITHOUT initialising any runtime (the parent of the ranks stays off the GPU): the
+    KFD topology's nodes with SIMDs, narrowed by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.  Falls back to asking a child process."""
+    n = 0
+    try:
+        root = '/sys/class/kfd/kfd/topology/nodes'
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, 'properties')) as f:
+                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = -1
+    if n < 0:                                         # no sysfs view: a child counts and exits
+        try:
+            out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'], capture_output=True,
+                                 text=True, timeout=300).stdout
+            n = int(out.strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+            n = 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
 
 
 def spawn_ranks(args):
@@ -581,6 +681,7 @@ def main():
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-config-legs', action='store_true', help="N=1: skip the `configs` legs (BASELINE's other single-GPU configurations)")
     ap.add_argument('--halo-ticks', type=int, default=4, help='N > 1: ticks between two halo exchanges (ghost zone depth)')
     ap.add_argument('--spawn-timeout', type=int, default=1500, help='N > 1 without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--force-dist', action='store_true', help='run the rank path even in a one-rank group (rehearsal)')

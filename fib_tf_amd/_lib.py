@@ -20,8 +20,16 @@ CHEBY, SKIP, CHRONIC, FAST, ALLVARS, ROW_INTERLEAVED, ZEROPAD, HOLD = 1, 2, 4, 8
 # -ffp-contract=off: FMAs appear only where the source writes them (policy hook P::mad).
 # -fno-slp-vectorize: SLP packs pairs of f32 ops into v_pk_* instructions, which issue at half rate on
 #   gfx950 (tools/ubench/valu.hip) and need v_mov shuffles: 11 % slower on the Fenton kernel.
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared', '-std=c++17',
-               '-Wall', '-Wno-unused-value', '-Wno-unused-result']
+# -fvisibility=hidden: the library exports the C ABI of include/fibhip.h and nothing else (the header pushes default
+#   visibility for its declarations).
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-fvisibility=hidden', '-fPIC', '-shared',
+               '-std=c++17', '-Wall', '-Wno-unused-value', '-Wno-unused-result']
+
+
+def _build_tag(so_path):
+    """-DFIB_BUILD_TAG for a non-stock build: every kernel symbol of the build carries it (csrc/models.hpp)"""
+    import re
+    return '-DFIB_BUILD_TAG=b_' + re.sub(r'[^0-9A-Za-z_]', '_', os.path.splitext(os.path.basename(so_path))[0])
 
 
 class FibhipError(RuntimeError):
@@ -134,6 +142,7 @@ SYMBOLS = {
     'fibhip_comm_exchange': ([_h, C.c_int, C.c_int], C.c_int),
     'fibhip_comm_free': ([_h], C.c_int),
     'fibhip_copy_bandwidth': ([C.c_int, C.c_size_t, C.c_int, _fp], C.c_int),
+    'fibhip_warm': ([C.c_int], C.c_int),
     'fibhip_module_load': ([C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ModuleDesc), C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_module_unload': ([C.c_void_p], C.c_int),
     'fibhip_launch_plan': ([_h, _ip, _ip], C.c_int),
@@ -141,6 +150,7 @@ SYMBOLS = {
     'fibhip_host_alloc': ([C.c_size_t, C.POINTER(C.c_void_p)], C.c_int),
     'fibhip_host_free': ([C.c_void_p], C.c_int),
     'fibhip_ticks_per_launch': ([_h], C.c_int),
+    'fibhip_launch_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
     'fibhip_plan_tile': ([_h, _ip, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -170,7 +180,7 @@ def build_custom(inc_path, so_path, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tmp = '%s.%d.tmp' % (so_path, os.getpid())
     cmd = [hipcc] + HIPCC_FLAGS + ['-DFIB_CUSTOM_ONLY', '-DFIB_CUSTOM_MODEL_INC="%s"' % os.path.abspath(inc_path),
-                                   SRC, '-o', tmp]
+                                   _build_tag(so_path), SRC, '-o', tmp]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
@@ -184,7 +194,7 @@ def build_specialised(defines, so_path, verbose=False):
     SGPR (kernel argument) at ~60 % (tools/ubench/valu2.hip), and the table feeds 96 multiply-adds per cell-step"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tmp = '%s.%d.tmp' % (so_path, os.getpid())
-    cmd = [hipcc] + HIPCC_FLAGS + list(defines) + [SRC, '-o', tmp]
+    cmd = [hipcc] + HIPCC_FLAGS + list(defines) + [_build_tag(so_path), SRC, '-o', tmp]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
@@ -215,6 +225,17 @@ def lib():
                               'fib_tf_amd has no CPU fallback')
         _lib = load(SO)
     return _lib
+
+
+_warmed = set()
+
+
+def warm(device=0):
+    """the stock library's code object first: called before any OTHER build of the library launches a kernel in this
+    process (include/fibhip.h fibhip_warm: under rocprofv3 the opposite order dies inside the HIP runtime)"""
+    if device not in _warmed:
+        check(lib().fibhip_warm(device))
+        _warmed.add(device)
 
 
 # ---- in-process builds of traced models: hiprtc -> code object -> fibhip_module_load ------------------------------
@@ -540,6 +561,13 @@ class Stepper:
         self._ck(self._L.fibhip_plan_tile(self._h, C.byref(w), C.byref(t), C.byref(r)))
         return w.value, t.value, r.value
 
+    def launch_stats(self):
+        """{'launches', 'ticks', 'mt_launches', 'mt_ticks'} since the handle was created"""
+        out = (C.c_longlong * 4)()
+        self._ck(self._L.fibhip_launch_stats(self._h, out))
+        return dict(zip(('launches', 'ticks', 'mt_launches', 'mt_ticks'), [int(x) for x in out]))
+
     def ticks_per_launch(self):
-        """consecutive ticks one launch covers (Courtemanche, fast policy, one device: 3; otherwise 1)"""
+        """consecutive ticks one launch can cover (Courtemanche, fast policy, one device: 3; Fenton / Beeler-Reuter on a
+        grid whose tiles are all resident at once: FIBHIP_MT_MAX, default 32; otherwise 1)"""
         return self._ck(self._L.fibhip_ticks_per_launch(self._h))

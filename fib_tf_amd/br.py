@@ -16,20 +16,25 @@ SPEC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_spec')
 _spec_cache = {}
 
 
-def specialised_library(table32, build=True, verbose=False):
-    """libfibhip with the 12x9 Chebyshev table compiled in (csrc/br_step.inc, FIB_BR_TABLE_INC); None when it
-    is neither cached nor buildable here (the caller then stays on the stock library)"""
+def specialised_tag(table32):
+    """what names a specialised build: the table, every source file and the compiler flags"""
     import hashlib
-    import subprocess
-    alt = os.environ.get('FIBHIP_BR_LIBRARY')           # tuning experiments (tools/ab.sh): another build for this table
-    if alt:
-        return _lib.load(alt)
     h = hashlib.sha1(table32.tobytes())
     for d in _lib.DEPS:
         with open(d, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(_lib.HIPCC_FLAGS).encode())
-    tag = h.hexdigest()[:16]
+    return h.hexdigest()[:16]
+
+
+def specialised_library(table32, build=True, verbose=False):
+    """libfibhip with the 12x9 Chebyshev table compiled in (csrc/br_step.inc, FIB_BR_TABLE_INC); None when it
+    is neither cached nor buildable here (the caller then stays on the stock library)"""
+    import subprocess
+    alt = os.environ.get('FIBHIP_BR_LIBRARY')           # tuning experiments (tools/ab.sh): another build for this table
+    if alt:
+        return _lib.load(alt)
+    tag = specialised_tag(table32)
     if tag in _spec_cache:
         return _spec_cache[tag]
     so = os.path.join(SPEC_DIR, 'libfibhip_br_%s.so' % tag)
@@ -141,6 +146,8 @@ class BeelerReuter(IonicModel):
                 and not os.environ.get('FIBHIP_VARIANT'):
             # (FIBHIP_VARIANT = a tuning sweep over kernel shapes only the stock library carries)
             self._library = specialised_library(self._table32())
+            if self._library is not None:
+                _lib.warm(getattr(self, 'device', 0))       # the stock library's kernels first (include/fibhip.h fibhip_warm)
         return super()._new_stepper(steps_per_tick, shard)
 
     def define(self, s1=True):

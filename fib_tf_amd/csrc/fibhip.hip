@@ -49,7 +49,7 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // kernel variants
 // ------------------------------------------------------------------------------------------
 constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
-constexpr int AT_MT_TICKS = 4;           // autotune times a multi-tick candidate as one launch of this many ticks
+constexpr int AT_MT_TICKS = 8;           // autotune times a multi-tick candidate as one launch of this many ticks
 constexpr int MT_MAX_TILES = 1024;        // epoch words allocated per handle (only grids of <= ncu tiles use them)
 static const char *const MT_DEAD_MSG =
     "a multi-tick launch gave up: a tile waited 2 s for a neighbouring tile (were all workgroups resident? is another "
@@ -455,7 +455,9 @@ struct fibhip_ctx {
     unsigned epoch_base;    // value of every epoch word between two launches
     bool epochs_stale;      // the tiling may have changed since the words were last written: zero them first
     int mt_max;             // most ticks one launch advances (<= 1: never)
-    int mt_cur;             // ticks the next launch waits for: 1 after any observation of the state, doubling up to mt_max
+    int mt_cur;             // ticks the next launch waits for: 1 after any observation of the state, then see fibhip_step
+    long long n_ticks, n_mt_launches, n_mt_ticks;   // fibhip_launch_stats
+    int mt_run, mt_run_prev;        // ticks launched since the last observation of the state / between the two before it
     bool mt_inflight;       // a multi-tick launch has been issued since the give-up word was last read
     bool dead;              // a multi-tick launch gave up waiting: the state is void
     int ncu;                // compute units of the device
@@ -858,6 +860,8 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->epoch_base = 0;
     h->epochs_stale = true;
     h->mt_cur = 1;
+    h->mt_run = h->mt_run_prev = 0;
+    h->n_ticks = h->n_mt_launches = h->n_mt_ticks = 0;
     h->mt_inflight = false;
     h->dead = false;
     {
@@ -1324,6 +1328,11 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
         owner = h;
     }
     h->launches++;
+    if (commit) {
+        h->n_mt_launches++;
+        h->n_mt_ticks += T;
+        h->n_ticks += T;
+    }
     h->mt_inflight = true;
     h->epoch_base += (unsigned)(T - 1);               // every tile raised its word once per tick boundary
     if (commit) memcpy(h->cur, nxt, sizeof nxt);
@@ -1610,6 +1619,7 @@ static int commit_impl(fibhip_t h)
     if (h->phase_of_tick != 2) return fail(FIBHIP_EINVAL, "step_commit: call step_interior first");
     if (split_tick(h, h->plan.back())) HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
     memcpy(h->cur, h->nxt, sizeof h->cur);
+    h->n_ticks += h->plan.empty() ? 1 : (h->plan[0].K > h->spt ? h->plan[0].K / h->spt : 1);
     if (h->use_agg && ends_cycle(h)) h->agg_ghost_dirty = true;   // the exchange of this tick replaced the ghost rows
     h->cpos = (h->cpos + 1) % h->cycle;
     h->phase_of_tick = 0;
@@ -1643,6 +1653,7 @@ static int launch_pending(fibhip_t h, int n)
                 h->pending -= T;
                 n -= T;
                 if (int rc = tick_mt(h, v, T)) return rc;
+                h->mt_run += T;
             }
             return 0;
         }
@@ -1658,8 +1669,13 @@ static int launch_pending(fibhip_t h, int n)
 // launch the ticks fibhip_step left pending; every entry point that observes or changes the state calls this first
 static int flush(fibhip_t h)
 {
-    h->mt_cur = 1;                                  // the caller is about to look: the next tick starts a new series
-    return launch_pending(h, h->pending);
+    const int rc = launch_pending(h, h->pending);
+    if (h->mt_run > 0) {                            // the caller is about to look: the next tick starts a new series
+        h->mt_run_prev = h->mt_run;
+        h->mt_run = 0;
+    }
+    h->mt_cur = 1;
+    return rc;
 }
 
 extern "C" int fibhip_step_edges(fibhip_t h)
@@ -1690,9 +1706,10 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // and the last accepted tick is held back when the next call may be a step_slow, which then rides on its launch
     // (fused_fn).  Whatever is held back is launched by the next entry point that observes or changes the state.
     // Fenton / Beeler-Reuter on a grid whose tiles are all resident at once: consecutive ticks become ONE launch whose
-    // tiles hand their rims to each other (tick_mt).  A launch goes out as soon as `mt_cur` ticks are waiting — 1 after
-    // any call that observes the state, so the device starts at once, then 2, 4, ... mt_max while the caller keeps
-    // stepping — and takes every waiting tick, up to mt_max.
+    // tiles hand their rims to each other (tick_mt).  A launch goes out as soon as `mt_cur` ticks are waiting and takes
+    // every waiting tick, up to mt_max.  mt_cur is 1 after any call that observes the state, so the device starts at once;
+    // then the rest of the series if the caller works in series of equal length (run() with an image() every n ticks, a
+    // benchmark region: the ticks between the last two observations), else 2, 4, ... mt_max while the caller keeps stepping.
     if (h->mt_max > 1 && nticks > 0) {
         if (int rc = check_ready(h)) return rc;
         if (!h->tuned)
@@ -1703,7 +1720,10 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
                 const int T = imin(h->pending, h->mt_max);
                 h->pending -= T;
                 if (int rc = tick_mt(h, v, T)) return rc;
-                h->mt_cur = imin(2 * h->mt_cur, h->mt_max);
+                const bool first = h->mt_run == 0;
+                h->mt_run += T;
+                const int rest = h->mt_run_prev - h->mt_run;
+                h->mt_cur = (first && rest >= 2) ? imin(rest, h->mt_max) : imin(2 * h->mt_cur, h->mt_max);
             }
             return 0;
         }
@@ -2189,6 +2209,19 @@ extern "C" int fibhip_module_unload(fibhip_module_t m)
     return 0;
 }
 
+extern "C" int fibhip_warm(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FIBHIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FIBHIP_EINVAL, "device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(copy_kernel, dim3(1), dim3(256), 0, 0, (const fib_v4f *)nullptr, (fib_v4f *)nullptr, (size_t)0);   // n = 0: touches nothing
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(0));
+    return 0;
+}
+
 extern "C" int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gbs)
 {
     if (!gbs || nbytes < (1u << 20) || reps < 1) return fail(FIBHIP_EINVAL, "copy_bandwidth: bad argument");
@@ -2277,6 +2310,16 @@ extern "C" int fibhip_ticks_per_launch(fibhip_t h)
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
     if (mt_variant(h)) return h->mt_max;
     return h->multi_max;
+}
+
+extern "C" int fibhip_launch_stats(fibhip_t h, long long out[4])
+{
+    if (!h || !out) return fail(FIBHIP_EINVAL, "launch_stats: null argument");
+    out[0] = h->launches;
+    out[1] = h->n_ticks;
+    out[2] = h->n_mt_launches;
+    out[3] = h->n_mt_ticks;
+    return 0;
 }
 
 extern "C" int fibhip_launch_plan(fibhip_t h, int *fused_steps, int *launches_per_tick)

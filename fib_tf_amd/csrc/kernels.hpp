@@ -24,6 +24,7 @@
 #include "models.hpp"
 
 namespace fib {
+FIB_TAG_BEGIN
 
 struct Geo {
     int H, W;        // rows / cols of this slab
@@ -1099,4 +1100,5 @@ __global__ void __launch_bounds__(256) copy_kernel(const fib_v4f *__restrict__ s
     if (i < n) dst[i] = src[i];
 }
 
+FIB_TAG_END
 }  // namespace fib

@@ -22,7 +22,20 @@
 #include <hip/hip_runtime.h>
 #endif
 
+// Builds of this translation unit other than the stock library (a Beeler-Reuter table baked in, a traced model compiled
+// in) put everything into an inline namespace named after the build: the same kernel then has a DIFFERENT symbol in every
+// code object a process may hold at once (tools that key kernels by name — rocprofv3's kernel trace — met two
+// `fib::copy_kernel` of two fat binaries in round 2 and crashed).
+#ifdef FIB_BUILD_TAG
+#define FIB_TAG_BEGIN inline namespace FIB_BUILD_TAG {
+#define FIB_TAG_END }
+#else
+#define FIB_TAG_BEGIN
+#define FIB_TAG_END
+#endif
+
 namespace fib {
+FIB_TAG_BEGIN
 
 #define FIB_DEV __device__ __forceinline__
 
@@ -681,4 +694,5 @@ struct CourtAgg : CourtT<false> {
 #include FIB_CUSTOM_MODEL_INC
 #endif
 
+FIB_TAG_END
 }  // namespace fib

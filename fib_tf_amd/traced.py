@@ -1044,4 +1044,7 @@ def _build(src, verbose=False, device=None):
             f.write(src)
         os.replace(tmp, inc)
         _lib.build_custom(inc, so, verbose=verbose)
-    return None if device is None else _lib.load(so)
+    if device is None:
+        return None
+    _lib.warm(device)                                 # the stock library's kernels first (include/fibhip.h fibhip_warm)
+    return _lib.load(so)

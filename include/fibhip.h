@@ -28,6 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: these entry points are ALL it exports (no kernel handle, host stub or
+ * template instance of one build can meet its namesake of another build of the same sources in one process). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FIBHIP_ABI_VERSION 1
 
@@ -242,6 +247,12 @@ int fibhip_module_unload(fibhip_module_t m);   /* after every handle created on 
  * per second, GB/s) — the achievable-bandwidth yardstick printed next to the roofline peak                  */
 int fibhip_copy_bandwidth(int device, size_t nbytes, int reps, float *gb_per_s);
 
+/* Launches one empty kernel of THIS build of the library on `device`, so that its code object is the first one the HIP
+ * runtime brings up.  fib_tf_amd calls it on the stock library before it uses any other build (a Beeler-Reuter table
+ * baked in, a traced model compiled in): under rocprofv3 (ROCm 7.2) the first launch from the stock library AFTER
+ * another build's kernels have run dies inside libamdhip64's launch path; the other order is fine.   */
+int fibhip_warm(int device);
+
 #define FIBHIP_COURT_NINTER 32
 int fibhip_court_inter(int device, int n, const float *V, int fast, float *out);
 
@@ -253,11 +264,23 @@ int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_per_wave);
 /* Consecutive ticks one launch can cover (1 = every tick is its own launch or launches).  Courtemanche under
  * FIBHIP_FAST on one device returns 3: fibhip_step() accepts ticks and launches them three at a time, temporally
  * blocked; whatever has been accepted but not launched is launched by the next call that observes or changes the
- * state (get/set_state, probe, pace, sync, step_slow ...), so no caller can see the difference.                  */
+ * state (get/set_state, probe, pace, sync, step_slow ...), so no caller can see the difference.
+ * Fenton / Beeler-Reuter grids whose tiles are all resident on the device at once (tiles <= compute units; one device,
+ * planar slab) return FIBHIP_MT_MAX (default 32): one launch then loops over up to that many ticks, its tiles re-reading
+ * only the rim of their compute box from their neighbours between two ticks (no TensorFlow counterpart: ionic.py:202-204
+ * issues one sess.run per tick).  A launch goes out as soon as the device would otherwise idle (see fibhip_step in
+ * csrc/fibhip.hip); FIBHIP_MT=0 switches the mode off.  A tile of such a launch that waits 2 s for a neighbour gives up:
+ * the next synchronising call returns FIBHIP_EHIP and the handle refuses further work.                           */
 int fibhip_ticks_per_launch(fibhip_t h);
+/* counters since fibhip_create: out[0] launches of any kernel, out[1] ticks advanced, out[2] multi-tick launches,
+ * out[3] ticks those advanced (profiling scripts turn per-launch hardware counters into per-tick figures with them)  */
+int fibhip_launch_stats(fibhip_t h, long long out[4]);
 
 const char *fibhip_last_error(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -600,6 +600,18 @@ def test_fenton_multi_tick_launch_count(gpu_lib, monkeypatch):
     st.step(70)
     ms, launches = st.time_end()
     assert launches == 3, launches
+    # series of equal length (run() with an image() every 10 ticks): the first tick at once, the other nine together
+    for _ in range(2):
+        for _ in range(10):
+            st.step(1)
+        st.get_state(0)
+    st.time_begin()
+    for _ in range(10):
+        st.step(1)
+    ms, launches = st.time_end()
+    assert launches == 2, launches
+    stats = st.launch_stats()
+    assert stats['ticks'] == 1 + 20 + 70 + 30 and stats['mt_ticks'] <= stats['ticks'] and stats['mt_launches'] >= 6, stats
     st.close()
 
 
@@ -1296,6 +1308,34 @@ def test_readback_into_page_locked_arrays(gpu_lib):
     st.step(3)
     assert not np.array_equal(st.get_state(0), init[0])
     st.close()
+
+
+def test_stock_library_kernel_after_specialised_library_kernel(gpu_lib, monkeypatch):
+    """two builds of the library in one process: a Beeler-Reuter handle runs kernels from the specialised build (table as
+    literals), then the first kernel launched from the STOCK library is the copy yardstick.  Under rocprofv3 this sequence
+    died in round 2 (kernels of the same name in two fat binaries); every non-stock build now carries a build tag in its
+    kernel symbols (csrc/models.hpp FIB_BUILD_TAG).  tools/prof_stock_after_spec.sh runs this test under the profiler."""
+    import subprocess
+    from fib_tf_amd import _lib
+    from fib_tf_amd.br import BeelerReuter
+    monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
+    m = BeelerReuter(cfg(96, 128, 0.809, 'fast', cheby=True))
+    m.define()
+    spec = m._library
+    if spec is None:
+        pytest.skip('no specialised build here (no compiler, none cached)')
+    assert spec._name != _lib.SO
+    m._stepper.step(7)
+    m._stepper.sync()
+    # no kernel symbol of the specialised build has a namesake in the stock library
+    def kernel_syms(path):
+        out = subprocess.check_output(['nm', '-D', '--defined-only', path]).decode()
+        return {l.split()[-1] for l in out.splitlines() if '_kernel' in l}
+    assert kernel_syms(spec._name) and not (kernel_syms(spec._name) & kernel_syms(_lib.SO))
+    assert _lib.copy_bandwidth(1 << 26, 2) > 100.0          # stock library, first launch from it
+    m._stepper.step(3)
+    m._stepper.sync()
+    assert np.isfinite(m._State['V'].eval()).all()
 
 
 def test_copy_bandwidth_yardstick(gpu_lib):
