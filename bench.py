@@ -64,7 +64,7 @@ def make_model(args, height=None, device=0, exact=None):
     exact = args.exact if exact is None else exact
     base = {'width': S, 'height': H, 'dt': 0.1, 'dt_per_plot': 10, 'duration': 1000, 'timeline': False,
             'timeline_name': 'timeline.json', 'save_graph': False, 'device': device, 'fast_math': not exact,
-            'halo_ticks': getattr(args, 'halo_ticks', 4)}
+            'halo_ticks': getattr(args, 'halo_ticks', 0), 'halo': getattr(args, 'halo', None)}
     if args.model == 'fenton':                        # fenton.py:156-171
         m = Fenton4v(dict(base, diff=1.5))
         m.add_hole_to_phase_field(256 * sc, H / 2.0, 30 * sc)
@@ -586,8 +586,9 @@ def bench_ranks(args):
     # stand-alone handle, ticks timed with HIP events on its stream: the block's kernels without any exchange
     kern = None
     if rank == 0 and hasattr(st, 'lh'):
+        espt = getattr(st, 'eng_spt', spt)                  # sub-steps per engine tick: 1 under --halo rows1
         probe = _lib.Stepper(m.MODEL_ID, st.lh, m.width, m.dt, m.diff, flags=m._flags() | _lib.ROW_INTERLEAVED, device=local,
-                             steps_per_tick=spt, global_height=H, row_offset=st.lo, ghost_top=st.gt, ghost_bottom=st.gb,
+                             steps_per_tick=espt, global_height=H, row_offset=st.lo, ghost_top=st.gt, ghost_bottom=st.gb,
                              library=m._library)
         m._configure_stepper(probe)
         if m.phase is not None:
@@ -596,7 +597,8 @@ def bench_ranks(args):
         probe.step(2 * halo_ticks)
         probe.sync()
         ms, launches = probe.time_steps(max(halo_ticks, 200 // halo_ticks * halo_ticks))
-        kern = (ms * 1000.0 / max(1, launches), launches, max(halo_ticks, 200 // halo_ticks * halo_ticks), probe.launch_plan()[0])
+        kern = (ms * 1000.0 / max(1, launches), launches, max(halo_ticks, 200 // halo_ticks * halo_ticks) * espt / float(spt),
+                probe.launch_plan()[0])
         probe.close()
 
     out = None
@@ -639,9 +641,12 @@ def bench_ranks(args):
                                                                                            {'fenton': 1, 'br': 2, 'court': 4}[args.model])), spt),
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
-                       'parallelism': 'row-block x%d; ghost zone %d rows (= %d ticks): one point-to-point send/recv pair per '
-                                      'neighbour every %d ticks, %d arrays in one contiguous message, interior '
-                                      'overlapped on a second stream on tall blocks' % (world, ghost, halo_ticks, halo_ticks, halo_n),
+                       'parallelism': ('row-block x%d; one ghost row of the potential, exchanged after every sub-step (%d per tick), '
+                                       'edge rows first, interior on a second stream' % (world, spt)) if getattr(st, 'halo_mode', '') == 'rows1' else
+                                      ('row-block x%d; ghost zone %d rows (= %d ticks): one point-to-point send/recv pair per '
+                                       'neighbour every %d ticks, %d arrays in one contiguous message, interior '
+                                       'overlapped on a second stream on tall blocks' % (world, ghost, halo_ticks, halo_ticks, halo_n)),
+                       'halo_scheme': getattr(st, 'halo_mode', 'ghost'),
                        'halo_transport': getattr(st, 'halo_path', 'none'), 'backend': backend,
                        'ranks_in_communicator': int(nranks.item()),
                        'halo_wait_s_max_rank': round(float(comm.item()), 4), 'setup_ticks': 2 * halo_ticks + args.setup // halo_ticks * halo_ticks,
@@ -682,7 +687,11 @@ def main():
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-config-legs', action='store_true', help="N=1: skip the `configs` legs (BASELINE's other single-GPU configurations)")
-    ap.add_argument('--halo-ticks', type=int, default=4, help='N > 1: ticks between two halo exchanges (ghost zone depth)')
+    ap.add_argument('--halo-ticks', type=int, default=0, help='N > 1: ticks between two halo exchanges (ghost zone depth); 0 = '
+                    'chosen from the block height (at most 4, extra rows within half of the block)')
+    ap.add_argument('--halo', default=None, choices=['ghost', 'rows1'],
+                    help="N > 1: 'ghost' (default) = multi-tick ghost zone of all arrays; 'rows1' = north_star's literal scheme, one "
+                         "ghost row of the potential exchanged after every sub-step, edge rows first, interior on a second stream")
     ap.add_argument('--spawn-timeout', type=int, default=1500, help='N > 1 without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--force-dist', action='store_true', help='run the rank path even in a one-rank group (rehearsal)')
     args = ap.parse_args()

@@ -1,6 +1,16 @@
 #!/usr/bin/env python3
-"""The reference's `court.py __main__` protocol (court.py:585-636), shortened: fast tick every iteration,
-'slow' + 'trend' every 10th, S2 at 350 ms, keep_state -> define(state=...) resume."""
+"""Atrial re-entry in the 21-variable Courtemanche model, in two stages, with the state handed from one to the next.
+
+Stage 1: a ring of tissue (everything outside a large disc and inside a small one is removed from the phase field); a
+wave is started at the left, a second stimulus breaks it.  Every tick assigns the four fast variables (V, Na_i and the
+two sodium gates); the other seventeen follow every tenth tick through the model's 'slow' operation, which is when the
+probe trace (potential and sodium concentration at the sheet's centre row) is sampled too.
+Stage 2: the final state of stage 1 continues on a sheet with a LARGER central obstacle (define(state=...)), the way a
+protocol changes the substrate under a running arrhythmia.
+
+    python examples/run_court.py [--size N] [--ms T] [--ms2 T] [--healthy] [--out FILE]
+"""
+import argparse
 import os
 import sys
 
@@ -9,33 +19,57 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fib_tf_amd.court import Courtemanche, cl_observer
 
-if __name__ == '__main__':
-    config = {'width': 512, 'height': 512, 'dt': 0.1, 'dt_per_plot': 10, 'diff': 0.809,
-              'duration': float(sys.argv[1]) if len(sys.argv) > 1 else 500, 'skip': False, 'cheby': True,
-              'timeline': False, 'timeline_name': 'timeline_court.json', 'save_graph': False}
-    m1 = Courtemanche(config)
-    m1.add_hole_to_phase_field(256, 256, 30)
-    m1.add_hole_to_phase_field(256, 256, 250, neg=True)
-    m1.define()
-    m1.add_pace_op('s2', 'luq', 10.0)
-    m1.cl_observer = cl_observer
-    s2 = m1.millisecond_to_step(350)
-    data = []
-    for i in m1.run(None, keep_state=True, block=False):
-        if i % 10 == 0:
-            m1.fire_op('slow')
-            m1.fire_op('trend')
-            data.append(m1._Trend.eval())
-        if i == s2:
-            m1.fire_op('s2')
+SLOW_EVERY = 10        # ticks between two 'slow' updates (the model integrates its slow set with 10 dt)
 
-    m2 = Courtemanche(dict(config, duration=50))
-    m2.add_hole_to_phase_field(256, 256, 100)
-    m2.add_hole_to_phase_field(256, 256, 250, neg=True)
-    m2.define(state=m1.state)
-    for i in m2.run(None):
-        if i % 10 == 0:
-            m2.fire_op('slow')
-            m2.fire_op('trend')
-            data.append(m2._Trend.eval())
-    np.savetxt('vol_na_2.dat', np.asarray(data))
+
+def ring(sheet, inner, outer):
+    c = sheet.width / 2.0
+    sheet.add_hole_to_phase_field(c, c, inner)
+    sheet.add_hole_to_phase_field(c, c, outer, neg=True)
+
+
+def advance(sheet, trace, stimulus_tick=None, keep=False):
+    for tick in sheet.run(None, keep_state=keep, block=False):
+        if tick % SLOW_EVERY == 0:
+            sheet.fire_op('slow')
+            sheet.fire_op('trend')
+            trace.append(sheet._Trend.eval())
+        if tick == stimulus_tick:
+            sheet.fire_op('break')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--ms', type=float, default=500.0, help='duration of stage 1')
+    ap.add_argument('--ms2', type=float, default=50.0, help='duration of stage 2')
+    ap.add_argument('--healthy', action='store_true',
+                    help='normal conductances (the model class defaults to the chronically remodelled parameter set)')
+    ap.add_argument('--out', default='court_trace.txt')
+    args = ap.parse_args()
+    n, scale = args.size, args.size / 512.0
+    common = {'width': n, 'height': n, 'dt': 0.1, 'diff': 0.809, 'dt_per_plot': 10, 'timeline': False,
+              'timeline_name': 'timeline_court.json', 'save_graph': False}
+
+    first = Courtemanche(dict(common, duration=args.ms))
+    first.chronic = not args.healthy
+    ring(first, 30 * scale, 250 * scale)
+    first.define()
+    first.add_pace_op('break', 'luq', 10.0)
+    first.cl_observer = cl_observer
+    trace = []
+    advance(first, trace, stimulus_tick=first.millisecond_to_step(350), keep=True)
+
+    second = Courtemanche(dict(common, duration=args.ms2))
+    second.chronic = not args.healthy
+    ring(second, 100 * scale, 250 * scale)
+    second.define(state=first.state)
+    advance(second, trace)
+
+    np.savetxt(args.out, np.asarray(trace))
+    print('%d probe samples (every %d ticks) written to %s; stage 1 ran %.0f Mcell-steps/s' % (
+        len(trace), SLOW_EVERY, args.out, n * n * first.samples / first.elapsed / 1e6))
+
+
+if __name__ == '__main__':
+    main()

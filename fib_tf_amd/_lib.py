@@ -95,6 +95,11 @@ class ModuleDesc(C.Structure):
                     ('nkernels', C.c_int), ('kernels', C.POINTER(ModuleKernel))]
 
 
+class TraceEvent(C.Structure):
+    _fields_ = [('name', C.c_char * 96), ('start_us', C.c_double), ('dur_us', C.c_double), ('K', C.c_int), ('tile_w', C.c_int),
+                ('tile_h', C.c_int), ('rows_per_wave', C.c_int), ('ticks', C.c_int)]
+
+
 class HaloMsg(C.Structure):
     _fields_ = [('offset', C.c_longlong), ('count', C.c_longlong), ('peer', C.c_int), ('send', C.c_int)]
 
@@ -151,6 +156,8 @@ SYMBOLS = {
     'fibhip_host_free': ([C.c_void_p], C.c_int),
     'fibhip_ticks_per_launch': ([_h], C.c_int),
     'fibhip_launch_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
+    'fibhip_trace_begin': ([_h], C.c_int),
+    'fibhip_trace_end': ([_h, C.POINTER(TraceEvent), C.c_int], C.c_int),
     'fibhip_plan_tile': ([_h, _ip, _ip, _ip], C.c_int),
     'fibhip_last_error': ([], C.c_char_p),
 }
@@ -560,6 +567,22 @@ class Stepper:
         w, t, r = C.c_int(), C.c_int(), C.c_int()
         self._ck(self._L.fibhip_plan_tile(self._h, C.byref(w), C.byref(t), C.byref(r)))
         return w.value, t.value, r.value
+
+    def trace_begin(self):
+        self._ck(self._L.fibhip_trace_begin(self._h))
+
+    def trace_end(self):
+        """[{'name', 'ts' (us from the first launch), 'dur' (us), 'K', 'tile', 'ticks'}] of the launches since trace_begin"""
+        ev = (TraceEvent * 64)()
+        n = self._ck(self._L.fibhip_trace_end(self._h, ev, 64))
+        return [{'name': e.name.decode(), 'ts': e.start_us, 'dur': e.dur_us, 'K': e.K, 'tile': (e.tile_w, e.tile_h, e.rows_per_wave),
+                 'ticks': e.ticks} for e in ev[:n]]
+
+    def trace_tick(self):
+        """one tick with every launch between two HIP events (the timeline of ionic.py:231-241)"""
+        self.trace_begin()
+        self.step(1)
+        return self.trace_end()
 
     def launch_stats(self):
         """{'launches', 'ticks', 'mt_launches', 'mt_ticks'} since the handle was created"""

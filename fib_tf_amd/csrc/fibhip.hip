@@ -55,6 +55,9 @@ static const char *const MT_DEAD_MSG =
     "a multi-tick launch gave up: a tile waited 2 s for a neighbouring tile (were all workgroups resident? is another "
     "process holding the GPU?); the state of this handle is void — FIBHIP_MT=0 runs one launch per tick";
 
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
 constexpr int FIB_MAXVAR = 26;   // CourtAgg: 21 state arrays + 5 aggregates (CourtemancheUS: 22)
 
 struct LaunchCtx {
@@ -461,11 +464,20 @@ struct fibhip_ctx {
     bool mt_inflight;       // a multi-tick launch has been issued since the give-up word was last read
     bool dead;              // a multi-tick launch gave up waiting: the state is void
     int ncu;                // compute units of the device
+    // fibhip_trace_begin / _end: the launches in between, each between two HIP events
+    struct TraceRec {
+        hipEvent_t e0, e1;
+        char name[96];
+        int K, TX, TY, R, ticks;
+    };
+    std::vector<TraceRec> trace;
+    bool tracing;
     fibhip_module *mod;     // FIBHIP_CUSTOM on a run-time module (fibhip_module_load), or null
     bool tuned;             // the plan has been checked against the other tile shapes on this very geometry (autotune)
     launch_fn fused_fn;     // Courtemanche: tick + 'slow' in one launch, or null
     int cycle, cpos;        // ghost zone = cycle * steps_per_tick rows: the halo is exchanged every `cycle` ticks;
                             // cpos = ticks done since the last exchange
+    int span;               // ticks the launch being issued covers (1; T while tick_multi fuses T Courtemanche ticks)
     void *comm;             // ncclComm_t of the direct halo path (fibhip_comm_*), or null
     float *probe_host;      // pinned
     float *stage;           // pinned staging buffer for get_state/set_state (one array), allocated on first use
@@ -689,9 +701,12 @@ static int build_plan(fibhip_ctx *h)
     // ticks until a launch is full; every entry point that observes the state launches what is pending first)
     h->multi_max = 1;
     for (int T = 2; T <= 3; ++T) h->plan_multi[T].clear();
-    if (h->use_agg && h->mode == CourtAgg::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 && !h->d.ghost_top &&
-        !h->d.ghost_bottom && !getenv("FIBHIP_NO_MULTI")) {
-        for (int T = 2; T <= 3; ++T) {
+    // (row blocks: the ticks between two halo exchanges are fused the same way — the ghost zone must be deep enough for the
+    // fused ticks to stay inside the exchange cycle; the tick that ends the cycle stays a launch of its own)
+    const bool shard = h->d.ghost_top || h->d.ghost_bottom;
+    if (h->use_agg && h->mode == CourtAgg::MODE_FAST && h->plan.size() == 1 && h->plan[0].K == 1 && (!shard || h->cycle >= 3) &&
+        !getenv("FIBHIP_NO_MULTI")) {
+        for (int T = 2; T <= (shard ? imin(3, h->cycle - 1) : 3); ++T) {
             int w[3];
             const char *e = getenv(T == 2 ? "FIBHIP_COURT_MULTI2" : "FIBHIP_COURT_MULTI3");
             const bool have = e && sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]) == 3;
@@ -781,6 +796,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         return fail(FIBHIP_EINVAL, "ghost width %d < steps_per_tick %d", ming, h->spt);
     h->cycle = (desc->ghost_top || desc->ghost_bottom) ? ming / h->spt : 1;
     h->cpos = 0;
+    h->span = 1;
 
     // scalars: every Python-float product is formed in double and rounded once
     const double dt = desc->dt, diff = desc->diff;
@@ -855,6 +871,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->fused_fn = nullptr;
     h->comm = nullptr;
     h->tuned = false;
+    h->tracing = false;
     h->xbuf = nullptr;
     h->epochs = nullptr;
     h->epoch_base = 0;
@@ -917,6 +934,10 @@ extern "C" int fibhip_destroy(fibhip_t h)
     if (h->agg) hipFree(h->agg);
     if (h->xbuf) hipFree(h->xbuf);
     if (h->epochs) hipFree(h->epochs);
+    for (auto &r : h->trace) {
+        if (r.e0) hipEventDestroy(r.e0);
+        if (r.e1) hipEventDestroy(r.e1);
+    }
     mt_forget(h);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->stage) hipHostFree(h->stage);
@@ -1192,6 +1213,39 @@ static void fill_ptrs(fibhip_ctx *h, LaunchCtx &c, int K, const int *cur, int *n
     c.consts = consts_of(h);
 }
 
+// ---- timeline (fibhip_trace_begin / _end) ------------------------------------------------------------------------------
+static int trace_open(fibhip_ctx *h, hipStream_t st, const char *family, int K, int TX, int TY, int NT, int ticks)
+{
+    if (!h->tracing) return 0;
+    fibhip_ctx::TraceRec r;
+    r.e0 = r.e1 = nullptr;
+    HIPCHK(hipEventCreate(&r.e0));
+    HIPCHK(hipEventCreate(&r.e1));
+    r.K = K; r.TX = TX; r.TY = TY; r.R = NT < 0 ? (NT < -32 ? -NT - 32 : -NT) : 0; r.ticks = ticks;
+    if (TX > 0 && NT < 0)
+        snprintf(r.name, sizeof r.name, "%s<K=%d, tile %dx%d, %d rows per wave%s>", family, K, TX, TY, r.R,
+                 ticks > 1 ? ", several ticks" : "");
+    else if (TX > 0)
+        snprintf(r.name, sizeof r.name, "%s<K=%d, tile %dx%d, %d threads>", family, K, TX, TY, NT);
+    else
+        snprintf(r.name, sizeof r.name, "%s", family);
+    HIPCHK(hipEventRecord(r.e0, st));
+    h->trace.push_back(r);
+    return 0;
+}
+static int trace_close(fibhip_ctx *h, hipStream_t st)
+{
+    if (!h->tracing || h->trace.empty()) return 0;
+    HIPCHK(hipEventRecord(h->trace.back().e1, st));
+    return 0;
+}
+static const char *family_of(const Variant *v)
+{
+    if (!v) return "kernel";
+    if (v->kern) return v->kind == MK_POINTWISE ? "pointwise_kernel (generated)" : (v->kind == MK_STRIP ? "strip_kernel (generated)" : "tick_kernel (generated)");
+    return v->NT < -32 ? "rows_kernel" : (v->NT < 0 ? "strip_kernel" : "tick_kernel");
+}
+
 // one launch over the rows [r0, r1) and, optionally, a second band [rb0, rb1)
 static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, LaunchCtx &c, int r0, int r1, int rb0 = 0,
                         int rb1 = 0)
@@ -1209,23 +1263,24 @@ static int launch_range(fibhip_ctx *h, hipStream_t st, const PlanItem &it, Launc
         c.nvar = h->nvar;
         c.consts_bytes = h->mod ? h->mod->consts_bytes : 0;
     }
+    if (int rc = trace_open(h, st, family_of(it.v), it.K, it.TX, it.TY, it.v ? it.v->NT : 0, it.K > h->spt ? it.K / h->spt : 1)) return rc;
     HIPCHK(it.fn(st, c));
+    if (int rc = trace_close(h, st)) return rc;
     h->launches++;
     return 0;
 }
 
-static inline int imax(int a, int b) { return a > b ? a : b; }
-static inline int imin(int a, int b) { return a < b ? a : b; }
 
 // rows launch `l` of the plan has to produce: the owned rows grown by the sub-steps still to come
 // (those rows are the halo of the later launches of the same tick), clipped to the slab
 // Communication-avoiding ghost zone: with ghost = cycle * steps_per_tick rows the neighbours' rows are
 // exchanged only every `cycle` ticks; tick j of a cycle also advances the (cycle-1-j) * spt ghost rows
 // next to the owned block, which are the halo of the ticks still to come.
-static inline int ext_rows(const fibhip_ctx *h) { return (h->cycle - 1 - h->cpos) * h->spt; }
+// (a launch that fuses `span` ticks leaves the rows the ticks AFTER it still need)
+static inline int ext_rows(const fibhip_ctx *h) { return (h->cycle - h->cpos - h->span) * h->spt; }
 static inline bool ends_cycle(const fibhip_ctx *h)
 {
-    return (h->d.ghost_top || h->d.ghost_bottom) && h->cpos == h->cycle - 1;
+    return (h->d.ghost_top || h->d.ghost_bottom) && h->cpos + h->span == h->cycle;
 }
 // On the tick that ends a cycle the strips the neighbours wait for can be launched first (main stream) and
 // the rest of the block on a second stream, so that the messages overlap the interior.  A fused launch is
@@ -1324,7 +1379,9 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
             HIPCHK(hipEventRecord(owner->ev_main, owner->s0));
             HIPCHK(hipStreamWaitEvent(h->s0, owner->ev_main, 0));
         }
+        if (int rc = trace_open(h, h->s0, "strip_mt_kernel", v->K, v->TX, v->TY, v->NT, T)) return rc;
         HIPCHK(v->fn_mt(h->s0, c));
+        if (int rc = trace_close(h, h->s0)) return rc;
         owner = h;
     }
     h->launches++;
@@ -1621,7 +1678,7 @@ static int commit_impl(fibhip_t h)
     memcpy(h->cur, h->nxt, sizeof h->cur);
     h->n_ticks += h->plan.empty() ? 1 : (h->plan[0].K > h->spt ? h->plan[0].K / h->spt : 1);
     if (h->use_agg && ends_cycle(h)) h->agg_ghost_dirty = true;   // the exchange of this tick replaced the ghost rows
-    h->cpos = (h->cpos + 1) % h->cycle;
+    h->cpos = (h->cpos + h->span) % h->cycle;
     h->phase_of_tick = 0;
     return 0;
 }
@@ -1636,9 +1693,14 @@ static int tick_now(fibhip_t h)
 // T consecutive ticks as one launch (T <= multi_max)
 static int tick_multi(fibhip_t h, int T)
 {
+    // on a row block a fused launch stays inside the exchange cycle: the tick that ends it is the caller's
+    // step_edges / exchange / step_interior / step_commit
+    if (h->d.ghost_top || h->d.ghost_bottom) T = imax(1, imin(T, h->cycle - 1 - h->cpos));
     if (T <= 1) return tick_now(h);
     h->plan.swap(h->plan_multi[T]);
+    h->span = T;
     const int rc = tick_now(h);
+    h->span = 1;
     h->plan.swap(h->plan_multi[T]);
     return rc;
 }
@@ -1646,7 +1708,7 @@ static int tick_multi(fibhip_t h, int T)
 // launch `n` of the ticks fibhip_step has deferred, the fewest launches first
 static int launch_pending(fibhip_t h, int n)
 {
-    if (n > 0)
+    if (n > 0 && !h->tracing)
         if (const Variant *v = mt_variant(h)) {
             while (n > 0) {
                 const int T = imin(h->mt_max, n);
@@ -1658,7 +1720,8 @@ static int launch_pending(fibhip_t h, int n)
             return 0;
         }
     while (n > 0) {
-        const int T = imin(h->multi_max, n);
+        int T = imin(h->multi_max, n);
+        if ((h->d.ghost_top || h->d.ghost_bottom) && T > 1) T = imax(1, imin(T, h->cycle - 1 - h->cpos));
         h->pending -= T;
         n -= T;
         if (int rc = tick_multi(h, T)) return rc;
@@ -1710,7 +1773,7 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // every waiting tick, up to mt_max.  mt_cur is 1 after any call that observes the state, so the device starts at once;
     // then the rest of the series if the caller works in series of equal length (run() with an image() every n ticks, a
     // benchmark region: the ticks between the last two observations), else 2, 4, ... mt_max while the caller keeps stepping.
-    if (h->mt_max > 1 && nticks > 0) {
+    if (h->mt_max > 1 && nticks > 0 && !h->tracing) {
         if (int rc = check_ready(h)) return rc;
         if (!h->tuned)
             if (int rc = autotune(h)) return rc;
@@ -1728,8 +1791,8 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
             return 0;
         }
     }
-    const int reserve = h->fused_fn ? 1 : 0;
-    const int cap = (h->multi_max > 1 ? h->multi_max - 1 : 0) + reserve;
+    const int reserve = (h->fused_fn && !h->tracing) ? 1 : 0;
+    const int cap = ((h->multi_max > 1 && !h->tracing) ? h->multi_max - 1 : 0) + reserve;
     if (cap > 0 && nticks > 0) {
         if (int rc = check_ready(h)) return rc;           // a deferred tick must not fail later, in someone else's call
         if (!h->tuned)                                    // (here, not inside a launch: the plans are being chosen)
@@ -1737,7 +1800,8 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     }
     h->pending += nticks;
     while (h->pending > cap) {
-        const int T = imin(h->multi_max, h->pending - reserve);
+        int T = h->tracing ? 1 : imin(h->multi_max, h->pending - reserve);
+        if ((h->d.ghost_top || h->d.ghost_bottom) && T > 1) T = imax(1, imin(T, h->cycle - 1 - h->cpos));
         h->pending -= T;
         if (int rc = tick_multi(h, T)) return rc;
     }
@@ -1772,7 +1836,9 @@ static int run_pointwise_mode(fibhip_t h, launch_fn fn, const Variant *mv, int r
         c.g.r1 = row1;
     }
     c.sub0 = 0;
+    if (int rc = trace_open(h, h->s0, mv ? "pointwise_kernel (generated)" : "pointwise_kernel", 1, 0, 0, 0, 1)) return rc;
     HIPCHK(fn(h->s0, c));
+    if (int rc = trace_close(h, h->s0)) return rc;
     h->launches++;
     return 0;
 }
@@ -1847,8 +1913,10 @@ extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, 
     FLUSH(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "pace inside an open tick");
     const Geo g = base_geo(h);
+    if (int rc = trace_open(h, h->s0, "pace_kernel", 1, 0, 0, 0, 1)) return rc;
     hipLaunchKernelGGL(pace_kernel, dim3(1024), dim3(256), 0, h->s0, g, h->slab[h->cur[0]], r0, r1, c0, c1, v, min_v);   // variable 0 starts at the slab base in both layouts
     HIPCHK(hipGetLastError());
+    if (int rc = trace_close(h, h->s0)) return rc;
     h->launches++;
     return 0;
 }
@@ -2291,7 +2359,8 @@ extern "C" int fibhip_halo_vars(fibhip_t h)
 extern "C" int fibhip_halo_due(fibhip_t h)
 {
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
-    return ends_cycle(h) ? 1 : 0;
+    // (ticks fibhip_step has accepted but not launched yet count: the NEXT tick is the one asked about)
+    return ((h->d.ghost_top || h->d.ghost_bottom) && (h->cpos + h->pending) % h->cycle == h->cycle - 1) ? 1 : 0;
 }
 
 extern "C" int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_per_wave)
@@ -2310,6 +2379,44 @@ extern "C" int fibhip_ticks_per_launch(fibhip_t h)
     if (!h) return fail(FIBHIP_EINVAL, "null handle");
     if (mt_variant(h)) return h->mt_max;
     return h->multi_max;
+}
+
+extern "C" int fibhip_trace_begin(fibhip_t h)
+{
+    NEED(h);
+    FLUSH(h);
+    if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "trace_begin inside an open tick");
+    for (auto &r : h->trace) {
+        if (r.e0) hipEventDestroy(r.e0);
+        if (r.e1) hipEventDestroy(r.e1);
+    }
+    h->trace.clear();
+    h->tracing = true;
+    return 0;
+}
+
+extern "C" int fibhip_trace_end(fibhip_t h, fibhip_trace_event *out, int max_events)
+{
+    NEED(h);
+    if (!h->tracing) return fail(FIBHIP_EINVAL, "trace_end without trace_begin");
+    if (!out || max_events < 1) return fail(FIBHIP_EINVAL, "trace_end: bad argument");
+    FLUSH(h);
+    h->tracing = false;
+    HIPCHK(wait_stream(h->s1));
+    SYNC_S0(h);
+    int n = 0;
+    for (const auto &r : h->trace) {
+        if (n >= max_events) break;
+        float t0 = 0.f, dur = 0.f;
+        HIPCHK(hipEventElapsedTime(&t0, h->trace[0].e0, r.e0));
+        HIPCHK(hipEventElapsedTime(&dur, r.e0, r.e1));
+        fibhip_trace_event &e = out[n++];
+        memcpy(e.name, r.name, sizeof e.name);
+        e.start_us = t0 * 1e3;
+        e.dur_us = dur * 1e3;
+        e.K = r.K; e.tile_w = r.TX; e.tile_h = r.TY; e.rows_per_wave = r.R; e.ticks = r.ticks;
+    }
+    return n;
 }
 
 extern "C" int fibhip_launch_stats(fibhip_t h, long long out[4])

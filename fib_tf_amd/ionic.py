@@ -176,11 +176,14 @@ class IonicModel:
                 self.state[s] = self._State[s].eval()
         st.sync()
         elapsed = time.time() - then
-        if self.timeline:                        # ionic.py:231-241: trace one more tick
-            ms, launches = st.time_steps(1)
-            fused, per_tick = st.launch_plan()
-            trace = {'traceEvents': [{'name': 'fibhip tick (%d launches, %d sub-steps fused)' % (launches, fused),
-                                      'ph': 'X', 'ts': 0, 'dur': ms * 1000.0, 'pid': 0, 'tid': 0}]}
+        if self.timeline:                        # ionic.py:231-241: trace one more tick, write a Chrome trace
+            events = st.trace_tick()             # every launch between two HIP events (+ the halo exchange on row blocks)
+            trace = {'traceEvents': [
+                {'name': e['name'], 'cat': 'halo' if e.get('host_clock') else 'kernel', 'ph': 'X', 'ts': e['ts'], 'dur': e['dur'],
+                 'pid': 0, 'tid': 1 if e.get('host_clock') else 0,
+                 'args': {'sub_steps_fused': e['K'], 'tile': '%dx%d' % e['tile'][:2], 'rows_per_wave': e['tile'][2],
+                          'ticks': e['ticks'], 'clock': 'host' if e.get('host_clock') else 'HIP events on the stream'}}
+                for e in events]}
             with open(self.timeline_name, 'w') as f:
                 json.dump(trace, f)
         self.elapsed = elapsed
@@ -224,7 +227,8 @@ class IonicModel:
         if shard and world > 1:
             st = ShardedStepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
                                 device=self.device, steps_per_tick=steps_per_tick,
-                                halo_ticks=getattr(self, 'halo_ticks', 4), library=self._library)
+                                halo_ticks=getattr(self, 'halo_ticks', 0), library=self._library,
+                                halo_mode=getattr(self, 'halo', None))
         else:
             st = _lib.Stepper(self.MODEL_ID, self.height, self.width, self.dt, self.diff, flags=self._flags(),
                               device=self.device, steps_per_tick=steps_per_tick, library=self._library)

@@ -103,7 +103,7 @@ class ShardedStepper:
     """same surface as `_lib.Stepper`, for one row block of a grid shared by all ranks"""
 
     def __init__(self, model_id, height, width, dt, diff, flags=0, device=0, steps_per_tick=0,
-                 engine_factory=None, group=None, halo_ticks=4, library=None):
+                 engine_factory=None, group=None, halo_ticks=0, library=None, halo_mode=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -118,15 +118,38 @@ class ShardedStepper:
         else:
             nvar, spt = engine_factory.nvar(model_id), steps_per_tick or engine_factory.default_steps(model_id)
         self.nvar, self.steps_per_tick = nvar, spt
+        # Two halo schemes.  'ghost' (default): a ghost zone several ticks deep, ALL arrays exchanged once per cycle, the
+        # ticks in between recompute the ghost rows they still need.  'rows1': the scheme BASELINE's north_star spells
+        # out — ONE ghost row of the potential alone, exchanged after every SUB-step (the other arrays are pointwise:
+        # nobody reads their ghost rows), one sub-step per launch, the block's edge rows first and its interior on the
+        # second stream while the rows travel.  Same arithmetic, bit-identical results; kept so that the two can be
+        # timed against each other on a node with xGMI.
+        self.halo_mode = halo_mode or os.environ.get('FIBTF_HALO_MODE', 'ghost')
+        if self.halo_mode not in ('ghost', 'rows1'):
+            raise ValueError("halo mode %r: 'ghost' or 'rows1'" % (self.halo_mode,))
+        self.sub = 1                                       # engine ticks per tick of the model
+        if self.halo_mode == 'rows1':
+            if flags & _lib.SKIP:
+                raise ValueError("'rows1' runs one sub-step per engine tick: Beeler-Reuter's `skip` schedule (slow gates on "
+                                 "the first sub-step of a tick) needs the tick as a unit — use the ghost-zone scheme")
+            self.sub, spt, halo_ticks = spt, 1, 1
         self.blocks = row_blocks(height, self.world)
         self.row0, self.rows = self.blocks[self.rank]
-        if min(n for _, n in self.blocks) < max(spt, 2):
+        rows_min = min(n for _, n in self.blocks)
+        if rows_min < max(spt, 2):
             raise ValueError('row blocks of %d rows are thinner than the %d-row halo: use fewer ranks or a taller '
-                             'grid' % (min(n for _, n in self.blocks), spt))
+                             'grid' % (rows_min, spt))
         # ghost zone = m ticks deep: the halo is exchanged every m-th tick only, the ticks in between recompute
-        # the ghost rows they still need (a message costs far more than 4 x spt extra rows of compute)
-        m = max(1, min(int(halo_ticks), min(n for _, n in self.blocks) // spt))
+        # the ghost rows they still need (a message costs far more than a few extra rows of compute).  Tick j of a cycle
+        # advances (m-1-j)*spt extra rows per neighbour, on average spt*(m-1)/2: unless the caller fixes m, it is the
+        # deepest zone (at most 4 ticks) whose extra rows stay within half of the block's own rows, 2 * spt*(m-1)/2 <=
+        # rows/2 (512 rows over 8 ranks: 64-row blocks, m = 4: 30 extra rows per tick on average).
+        if halo_ticks and int(halo_ticks) > 0:
+            m = max(1, min(int(halo_ticks), rows_min // spt))
+        else:
+            m = max(1, min(4, rows_min // spt, 1 + rows_min // (2 * spt)))
         self.halo_ticks = m
+        self.eng_spt = spt                                  # sub-steps per ENGINE tick (1 under 'rows1')
         self.g = m * spt
         self.gt = self.g if self.rank > 0 else 0
         self.gb = self.g if self.rank < self.world - 1 else 0
@@ -149,6 +172,7 @@ class ShardedStepper:
         self.recv_up = mk() if self.up is not None else None
         self.recv_down = mk() if self.down is not None else None
         self._op_cache = {}
+        self._trace_t0, self._trace_ev = None, []
         self.comm_s = 0.0
         # Halo transport on RCCL.  Default: torch.distributed's batch_isend_irecv on the slab views (one contiguous
         # [g, nvar, width] block each way).  FIBTF_HALO=direct (opt-in): the library issues the grouped
@@ -320,11 +344,30 @@ class ShardedStepper:
                 if self.down is not None:
                     self._slab_view(v, True)[b:].copy_(self.recv_down[v])
         self.comm_s += time.perf_counter() - t0
+        if self._trace_t0 is not None:                      # trace_tick: the exchange as an event of its own (host clock)
+            self._trace_ev.append({'name': 'halo exchange: %s, %d rows x %d arrays x %d columns per neighbour' % (
+                self.halo_path, g, self.halo_n, self.width), 'ts': (t0 - self._trace_t0) * 1e6,
+                'dur': (time.perf_counter() - t0) * 1e6, 'K': 0, 'tile': (0, 0, 0), 'ticks': 0, 'host_clock': True})
         e.step_commit()
 
     def step(self, nticks=1):
-        for _ in range(nticks):
+        for _ in range(nticks * self.sub):
             self._tick()
+
+    def trace_tick(self):
+        """one whole exchange cycle (halo_ticks ticks): this rank's launches between HIP events + the halo exchange as its
+        own event, timed on the host clock from its first enqueue to the last completed message"""
+        if not hasattr(self.eng, 'trace_begin'):
+            self.step(max(1, self.halo_ticks // self.sub))
+            return []
+        self._trace_ev = []
+        self.eng.trace_begin()
+        self._trace_t0 = time.perf_counter()
+        try:
+            self.step(self.halo_ticks)                      # ('rows1': one tick = its sub-steps, each with an exchange)
+        finally:
+            self._trace_t0 = None
+        return self.eng.trace_end() + self._trace_ev
 
     def step_slow(self):
         self.eng.step_slow()                                # pointwise: no halo needed

@@ -276,6 +276,18 @@ int fibhip_ticks_per_launch(fibhip_t h);
  * out[3] ticks those advanced (profiling scripts turn per-launch hardware counters into per-tick figures with them)  */
 int fibhip_launch_stats(fibhip_t h, long long out[4]);
 
+/* Timeline of the launches of a tick (ionic.py:231-241 traces one sess.run with TensorFlow's timeline and writes a
+ * Chrome trace): between trace_begin and trace_end every kernel launch of the handle is bracketed by a pair of HIP
+ * events on its stream and nothing is deferred (one launch = one tick); trace_end waits for the stream and returns
+ * the events: kernel family and shape, start relative to the first event and duration in microseconds.            */
+typedef struct fibhip_trace_event {
+    char name[96];            /* e.g. "strip_kernel<K=10, tile 44x25, 3 rows per wave>" */
+    double start_us, dur_us;
+    int K, tile_w, tile_h, rows_per_wave, ticks;
+} fibhip_trace_event;
+int fibhip_trace_begin(fibhip_t h);
+int fibhip_trace_end(fibhip_t h, fibhip_trace_event *out, int max_events);   /* returns the number of events */
+
 const char *fibhip_last_error(void);
 
 #if defined(__GNUC__) || defined(__clang__)

@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'libfib_oracle.so')
+SO_ASAN = os.path.join(HERE, 'libfib_oracle_asan.so')      # `make asan`: tests/test_oracle_sanitizers.py
 _lib = None
 
 FENTON_VARS = ['U', 'V', 'W', 'S']
@@ -42,9 +43,10 @@ def _p(a):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO):
+        alt = os.environ.get('FIB_ORACLE_LIB')           # another build of the same file (the sanitizer build)
+        if not alt and not os.path.exists(SO):
             build()
-        _lib = C.CDLL(SO)
+        _lib = C.CDLL(alt or SO)
         i, d, l, f = C.c_int, C.c_double, C.c_long, C.c_float
         sig = {
             'orc_enforce_boundary': [i, i, _fp, _fp],

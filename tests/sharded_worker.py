@@ -23,7 +23,7 @@ def run_case(rank, world, port, case, outdir):
         H, W, ticks = case['H'], case['W'], case['ticks']
         cfg = {'height': H, 'width': W, 'dt': 0.1, 'dt_per_plot': 10, 'diff': case['diff'], 'duration': 1000,
                'cheby': case.get('cheby', False), 'skip': case.get('skip', False),
-               'halo_ticks': case.get('halo_ticks', 4)}
+               'halo_ticks': case.get('halo_ticks', 4), 'halo': case.get('halo')}
         if case.get('engine', 'oracle') == 'oracle':
             # CPU rehearsal: the product's sharded driver on the oracle-backed test engine.  The engine is a
             # constructor argument of ShardedStepper, not a configuration key of the models: the test puts it there.
@@ -41,7 +41,7 @@ def run_case(rank, world, port, case, outdir):
         slow_trend = case['model'] in ('court', 'gated')
         if case['model'] in ('ap', 'ms', 'gated', 'mrfhn'):       # traced model files (tests/models/)
             from traced_cases import make_model
-            extra = {k: cfg[k] for k in ('halo_ticks', 'device') if k in cfg}
+            extra = {k: cfg[k] for k in ('halo_ticks', 'halo', 'device') if k in cfg}
             m = make_model(case['model'], H, W, case['hole'], **extra)
         else:
             cls = {'fenton': Fenton4v, 'br': BeelerReuter, 'court': Courtemanche}[case['model']]

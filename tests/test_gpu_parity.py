@@ -1158,7 +1158,7 @@ def test_c_abi_argument_checks(gpu_lib):
     c.close()
 
 
-def test_timeline_and_save_graph_keys(gpu_lib, tmp_path):
+def test_timeline_and_save_graph_keys(gpu_lib, tmp_path, monkeypatch):
     """config['timeline'] / ['timeline_name'] / ['save_graph'] of the reference (ionic.py:190-191,231-241):
     timeline writes a Chrome-trace JSON for one extra tick; save_graph is accepted and ignored"""
     import json
@@ -1171,8 +1171,31 @@ def test_timeline_and_save_graph_keys(gpu_lib, tmp_path):
         before = i
     assert before == 4
     tr = json.load(open(name))
-    ev = tr['traceEvents'][0]
-    assert ev['ph'] == 'X' and ev['dur'] > 0 and 'sub-steps fused' in ev['name']
+    fused, per_tick = m._stepper.launch_plan()
+    assert len(tr['traceEvents']) == per_tick                       # one event per launch of the traced tick
+    t_end = 0.0
+    for ev in tr['traceEvents']:
+        assert ev['ph'] == 'X' and ev['dur'] > 0 and ev['ts'] >= t_end - 1e-3 and 'kernel<K=%d' % fused in ev['name']
+        assert ev['args']['sub_steps_fused'] == fused and ev['args']['tile'].count('x') == 1
+        t_end = ev['ts'] + ev['dur']
+    # a plan of several launches per tick: one event each, in order
+    monkeypatch.setenv('FIBHIP_VARIANT', '2,60,18,-4')
+    m = Fenton4v(cfg(64, 64, 1.5, 'fast', duration=2, timeline=True, timeline_name=name))
+    m.define()
+    for _ in m.run():
+        pass
+    tr = json.load(open(name))
+    assert len(tr['traceEvents']) == 5 and all('strip_kernel<K=2, tile 60x18' in e['name'] for e in tr['traceEvents'])
+    # Courtemanche: the tick and the pending machinery do not hide launches from the trace
+    monkeypatch.delenv('FIBHIP_VARIANT')
+    from fib_tf_amd.court import Courtemanche
+    c = Courtemanche(cfg(64, 64, 0.809, 'fast', duration=1.05, timeline=True, timeline_name=name))
+    c.define()
+    for i in c.run():
+        if i % 10 == 0:
+            c.fire_op('slow')
+    tr = json.load(open(name))
+    assert len(tr['traceEvents']) >= 1 and tr['traceEvents'][0]['args']['ticks'] == 1
 
 
 # --------------------------------------------------------------------------------------------

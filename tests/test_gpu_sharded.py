@@ -30,6 +30,20 @@ CASES = [
          'cheby': True, 'skip': True, 'halo_ticks': 2}),
     (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 23, 's2': 12, 'amp': 10.0,
          'halo_ticks': 1}),
+    # Courtemanche with a ghost zone 4 and 6 ticks deep: the ticks between two exchanges run as ONE temporally blocked launch
+    # (3 ticks; 3 + 2) on the five aggregates of the slow variables, the tick that ends the cycle on its own
+    (2, {'model': 'court', 'H': 90, 'W': 66, 'diff': 0.809, 'hole': (30, 40, 6), 'ticks': 27, 's2': 12, 'amp': 10.0,
+         'halo_ticks': 4}),
+    (3, {'model': 'court', 'H': 120, 'W': 70, 'diff': 0.809, 'hole': (30, 50, 6), 'ticks': 31, 's2': 14, 'amp': 10.0,
+         'halo_ticks': 6}),
+    # north_star's literal halo scheme ('rows1'): one ghost row of the potential exchanged after every sub-step, one
+    # sub-step per launch, edge rows first and the interior on the second stream (with `split`)
+    (2, {'model': 'fenton', 'H': 128, 'W': 96, 'diff': 1.5, 'hole': (40, 64, 9), 'ticks': 4, 's2': 2, 'amp': 1.0,
+         'halo': 'rows1'}),
+    (3, {'model': 'br', 'H': 100, 'W': 64, 'diff': 0.809, 'hole': (30, 40, 8), 'ticks': 5, 's2': 2, 'amp': 10.0,
+         'cheby': True, 'skip': False, 'halo': 'rows1'}),
+    (2, {'model': 'court', 'H': 70, 'W': 66, 'diff': 0.809, 'hole': (30, 30, 6), 'ticks': 23, 's2': 12, 'amp': 10.0,
+         'halo': 'rows1'}),
     # four ranks on the one GPU (the box allows six processes on the card; the test runner itself holds it too)
     (4, {'model': 'fenton', 'H': 230, 'W': 70, 'diff': 1.5, 'hole': (30, 110, 9), 'ticks': 9, 's2': 4, 'amp': 1.0}),
     (4, {'model': 'br', 'H': 160, 'W': 64, 'diff': 0.809, 'hole': (30, 80, 8), 'ticks': 7, 's2': 3, 'amp': 10.0,
@@ -79,7 +93,8 @@ def single(case):
 
 
 @pytest.mark.parametrize('world,case', CASES,
-                         ids=['%s-x%d-h%s-%dx%d' % (c['model'], w, c.get('halo_ticks', 'd'), c['H'], c['W']) for w, c in CASES])
+                         ids=['%s-x%d-h%s-%dx%d%s' % (c['model'], w, c.get('halo_ticks', 'd'), c['H'], c['W'],
+                                                      '-' + c['halo'] if c.get('halo') else '') for w, c in CASES])
 @pytest.mark.parametrize('split', ['auto', 'split'])
 def test_sharded_hip_equals_single_handle(gpu_lib, world, case, tmp_path, split, monkeypatch):
     """split: force the two-stream edge-strips / interior launch on every exchange tick (the library only

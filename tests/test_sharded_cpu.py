@@ -111,6 +111,16 @@ CASES = [
          'halo_ticks': 1}),
     (8, {'model': 'fenton', 'H': 331, 'W': 24, 'diff': 1.5, 'hole': (12, 160, 6), 'ticks': 10, 's2': 3, 'amp': 1.0,
          'halo_ticks': 4}),
+    # north_star's literal halo scheme ('rows1'): ONE ghost row of the potential, exchanged after every sub-step
+    (2, {'model': 'fenton', 'H': 48, 'W': 40, 'diff': 1.5, 'hole': (20, 24, 5), 'ticks': 4, 's2': 2, 'amp': 1.0,
+         'halo': 'rows1'}),
+    (8, {'model': 'fenton', 'H': 93, 'W': 24, 'diff': 1.5, 'hole': (12, 46, 5), 'ticks': 3, 's2': 1, 'amp': 1.0,
+         'halo': 'rows1'}),
+    (3, {'model': 'court', 'H': 45, 'W': 56, 'diff': 0.809, 'hole': (28, 20, 5), 'ticks': 23, 's2': 11, 'amp': 10.0,
+         'halo': 'rows1'}),
+    # the ghost depth chosen from the block height (halo_ticks 0): 331 rows over 8 ranks -> 41-row blocks -> 3 ticks
+    (8, {'model': 'fenton', 'H': 331, 'W': 24, 'diff': 1.5, 'hole': (12, 160, 6), 'ticks': 8, 's2': 3, 'amp': 1.0,
+         'halo_ticks': 0}),
     # ONE array rewritten through set_state in the middle of an exchange cycle (the other arrays' outer ghost rows
     # are stale at that point: the cycle position must survive the call)
     (3, {'model': 'fenton', 'H': 150, 'W': 28, 'diff': 1.5, 'hole': (14, 70, 5), 'ticks': 11, 's2': 8, 'amp': 1.0,
@@ -119,8 +129,8 @@ CASES = [
 
 
 @pytest.mark.parametrize('world,case', CASES,
-                         ids=['%s-x%d-h%s%s' % (c['model'], w, c.get('halo_ticks', 'd'), '-poke' if c.get('poke') else '')
-                              for w, c in CASES])
+                         ids=['%s-x%d-h%s%s%s' % (c['model'], w, c.get('halo_ticks', 'd'), '-poke' if c.get('poke') else '',
+                                                  '-' + c['halo'] if c.get('halo') else '') for w, c in CASES])
 def test_sharded_equals_single_domain(world, case, tmp_path, orc):
     out = launch(world, case, tmp_path)
     want, trend = single_domain(case, orc)
@@ -128,6 +138,10 @@ def test_sharded_equals_single_domain(world, case, tmp_path, orc):
     assert np.array_equal(out['full'], want), 'max|d| = %g' % np.abs(out['full'] - want).max()
     if trend is not None:
         assert np.array_equal(out['trend'], trend)
+    if case.get('halo') == 'rows1':
+        assert int(out['halo_ticks']) == 1
+    if case.get('halo_ticks', 4) == 0:
+        assert int(out['halo_ticks']) == 3          # 41-row blocks, 10 sub-steps per tick: 1 + 41 // 20
 
 
 def test_bench_refuses_more_gpus_than_devices():
