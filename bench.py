@@ -289,6 +289,13 @@ def measure_single(args, exact, with_extras, snapshots=None):
     advance = driver_loop(m, st, s2, court)
     st.step(1)                                        # set-up, not a warm-up step: loads the code object
     st.sync()
+    # the interpreter's cyclic garbage collector: a full collection of this process takes ~40 ms (measured: one image() in
+    # ~1350 took 40 ms instead of 0.16, always the same one, none with the collector off) — a third of a 5000-tick region.
+    # Everything allocated so far is moved out of the collector's sight; what the timed loops allocate is freed by
+    # reference counting.
+    import gc
+    gc.collect()
+    gc.freeze()
     advance(args.setup)                               # set-up: clocks and caches in their steady state
     advance(args.warmup)
     walls = timed_regions(advance, st.sync, args.steps, args.repeats)

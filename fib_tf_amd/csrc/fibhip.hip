@@ -6,6 +6,7 @@
 // There is no CPU path in this library.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -461,6 +462,16 @@ struct fibhip_ctx {
     int mt_cur;             // ticks the next launch waits for: 1 after any observation of the state, then see fibhip_step
     long long n_ticks, n_mt_launches, n_mt_ticks;   // fibhip_launch_stats
     int mt_run, mt_run_prev;        // ticks launched since the last observation of the state / between the two before it
+    // run-ahead: a caller that alternates series of n ticks with ONE read-back (run() with image() every n ticks) gets the
+    // next n ticks launched BEFORE the read-back's copy is waited for; see fibhip_get_state_direct
+    int spec_n, spec_used;          // ticks computed ahead of the caller / how many of them fibhip_step has handed out
+    int spec_nxt[FIB_MAXVAR];       // where the state lives once all of them are handed out
+    int mt_run_prev2;               // the series before mt_run_prev
+    bool series_fresh;              // ticks have run since the last observation of the state
+    bool ahead_ok;                  // FIBHIP_AHEAD != 0
+    hipEvent_t ev_spec;
+    unsigned *snap_flags;           // page-locked: one word per tile, raised by the tiles of a launch that carries a read-back
+    unsigned snap_seq;
     bool mt_inflight;       // a multi-tick launch has been issued since the give-up word was last read
     bool dead;              // a multi-tick launch gave up waiting: the state is void
     int ncu;                // compute units of the device
@@ -877,7 +888,16 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->epoch_base = 0;
     h->epochs_stale = true;
     h->mt_cur = 1;
-    h->mt_run = h->mt_run_prev = 0;
+    h->mt_run = h->mt_run_prev = h->mt_run_prev2 = 0;
+    h->spec_n = h->spec_used = 0;
+    h->series_fresh = false;
+    h->snap_flags = nullptr;
+    h->snap_seq = 0;
+    {
+        const char *e = getenv("FIBHIP_AHEAD");
+        h->ahead_ok = !(e && atoi(e) == 0);
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
     h->n_ticks = h->n_mt_launches = h->n_mt_ticks = 0;
     h->mt_inflight = false;
     h->dead = false;
@@ -939,8 +959,10 @@ extern "C" int fibhip_destroy(fibhip_t h)
         if (r.e1) hipEventDestroy(r.e1);
     }
     mt_forget(h);
+    if (h->snap_flags) hipHostFree(h->snap_flags);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->stage) hipHostFree(h->stage);
+    if (h->ev_spec) hipEventDestroy(h->ev_spec);
     if (h->ev_main) hipEventDestroy(h->ev_main);
     if (h->ev_int) hipEventDestroy(h->ev_int);
     if (h->ev_t0) hipEventDestroy(h->ev_t0);
@@ -1038,6 +1060,9 @@ static Geo base_geo(const fibhip_ctx *h)
 // launches the tick fibhip_step may have left pending (defined with fibhip_step); every entry point that observes
 // or changes the state starts with it
 static int flush(fibhip_t h);
+struct Variant;
+static const Variant *mt_variant(const fibhip_ctx *h);
+static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_out, float *snap = nullptr, int snap_var = 0);
 #define FLUSH(h)                                                                                   \
     do {                                                                                           \
         if (int rc_ = flush(h)) return rc_;                                                        \
@@ -1111,6 +1136,72 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
     FLUSH(h);
     if (!dst || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "get_state_direct: bad var %d", var);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
+    // Run-ahead.  A caller that alternates series of n ticks with one read-back — IonicModel.run() with image() every n
+    // ticks, fenton.py:184-185 — would leave the device idle for the whole read-back (34 us of a 125 us series at
+    // 512x512).  When the last two series were equally long, the next n ticks are launched HERE, before the copy is waited
+    // for: the copy runs on the second stream from the slab the launch only reads.  fibhip_step then hands those ticks out
+    // without launching anything; any other call first makes the state what the caller has been told it is (flush()).
+    // The frame itself travels INSIDE that launch when the destination is page-locked memory the device can write
+    // (fibhip_host_alloc: what the Python binding hands in): every tile stores its cells of the array straight into it
+    // while it starts computing and raises a word in host memory at its first tick boundary; this thread polls those words.
+    // No copy engine, no blit kernel (which beside a grid that holds every compute unit would crawl: measured), no gap
+    // between two series.  Any other destination: the copy goes first on the same stream and the launch right behind it.
+    if (var >= 0 && h->ahead_ok && !h->tracing && h->series_fresh && h->mt_run_prev >= 2 && h->mt_run_prev == h->mt_run_prev2 &&
+        h->mt_run_prev <= h->mt_max && h->pitch == h->d.width) {
+        if (const Variant *mv = mt_variant(h)) {
+            const int L = h->mt_run_prev;
+            void *dev_dst = nullptr;
+            const bool in_launch = hipHostGetDevicePointer(&dev_dst, dst, 0) == hipSuccess && dev_dst != nullptr;
+            if (!in_launch) (void)hipGetLastError();
+            if (in_launch && !h->snap_flags) {
+                HIPCHK(hipHostMalloc((void **)&h->snap_flags, (size_t)MT_MAX_TILES * MT_SNAP_STRIDE * sizeof(unsigned), hipHostMallocDefault));
+                memset(h->snap_flags, 0, (size_t)MT_MAX_TILES * MT_SNAP_STRIDE * sizeof(unsigned));
+            }
+            if (in_launch) {
+                h->snap_seq++;
+                if (int rc = mt_launch(h, mv, L, false, h->spec_nxt, (float *)dev_dst, var)) return rc;
+            } else {
+                HIPCHK(hipMemcpyAsync(dst, h->slab[h->cur[var]] + (size_t)var * h->vstride, h->cells * sizeof(float), hipMemcpyDeviceToHost, h->s0));
+                HIPCHK(hipEventRecord(h->ev_spec, h->s0));
+                if (int rc = mt_launch(h, mv, L, false, h->spec_nxt)) return rc;
+            }
+            h->spec_n = L;
+            h->spec_used = 0;
+            h->series_fresh = false;
+            if (!in_launch) {
+                HIPCHK(wait_event(h->ev_spec));
+                return 0;
+            }
+            // every tile's word at this read-back's sequence number = every cell of the frame has landed
+            const int ntiles = ((h->d.width + mv->TX - 1) / mv->TX) * ((h->d.height + mv->TY - 1) / mv->TY);
+            volatile unsigned *fl = h->snap_flags;
+            const unsigned want = h->snap_seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            int next = 0;
+            long spins = 0;
+            while (next < ntiles) {
+                if (fl[(size_t)next * MT_SNAP_STRIDE] == want) {
+                    ++next;
+                    continue;
+                }
+                if ((++spins & 1023) == 0) {
+                    // a launch that has ended without raising every word gave up (or was never resident): report it
+                    if (hipStreamQuery(h->s0) == hipSuccess && fl[(size_t)next * MT_SNAP_STRIDE] != want) {
+                        h->spec_n = 0;
+                        SYNC_S0(h);
+                        return fail(FIBHIP_EHIP, "the launch that carried the read-back ended without delivering it");
+                    }
+                    (void)hipGetLastError();
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                        h->dead = true;
+                        return fail(FIBHIP_EHIP, "%s", MT_DEAD_MSG);
+                    }
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return 0;
+        }
+    }
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
     for (int v = v0; v < v1; ++v) {
         const float *src = h->slab[h->cur[v]] + (size_t)v * h->vstride;
@@ -1343,14 +1434,14 @@ static void mt_forget(fibhip_ctx *h)
 
 // one launch advancing T >= 2 ticks from the current slab into the other one; `commit`: the handle's state moves with it
 // (autotune times such launches without moving the state)
-static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
+static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_out, float *snap, int snap_var)
 {
     if (!h->xbuf) {
         if (hipMalloc((void **)&h->xbuf, 2 * (size_t)h->nvar * h->cells * sizeof(float)) != hipSuccess) {
             h->xbuf = nullptr;
             return fail(FIBHIP_ENOMEM, "hipMalloc of the tick-exchange buffer failed");
         }
-        const size_t words = (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE;
+        const size_t words = (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 2 * MT_EPOCH_STRIDE;
         if (hipMalloc((void **)&h->epochs, words * sizeof(unsigned)) != hipSuccess) {
             h->epochs = nullptr;
             return fail(FIBHIP_ENOMEM, "hipMalloc of the epoch words failed");
@@ -1358,7 +1449,7 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
         h->epochs_stale = true;
     }
     if (h->epochs_stale) {                            // first use, or the tiling may have changed: all words equal again
-        HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
+        HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 2 * MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
         h->epoch_base = 0;
         h->epochs_stale = false;
     }
@@ -1372,6 +1463,10 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
     c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
     c.mt.epoch0 = h->epoch_base;
     c.mt.nticks = T;
+    c.mt.snap = snap;
+    c.mt.snap_flag = h->snap_flags;
+    c.mt.snap_seq = h->snap_seq;
+    c.mt.snap_var = snap_var;
     {
         std::lock_guard<std::mutex> lock(g_mt.mu);
         fibhip_ctx *&owner = g_mt.owner[h->d.device];
@@ -1393,6 +1488,7 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit)
     h->mt_inflight = true;
     h->epoch_base += (unsigned)(T - 1);               // every tile raised its word once per tick boundary
     if (commit) memcpy(h->cur, nxt, sizeof nxt);
+    if (nxt_out) memcpy(nxt_out, nxt, sizeof nxt);
     return 0;
 }
 
@@ -1403,7 +1499,7 @@ static int tick_mt(fibhip_t h, const Variant *v, int T)
     if (T <= 1) return tick_now(h);
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
-    return mt_launch(h, v, T, true);
+    return mt_launch(h, v, T, true, nullptr);
 }
 
 // Plan selection by measurement (Fenton 4v and Beeler-Reuter).  The K-fused kernels exist in a family of tile shapes
@@ -1533,7 +1629,7 @@ static int autotune(fibhip_ctx *h)
             HIPCHK(hipEventRecord(h->ev_t0, h->s0));
             int sub = 0;
             if (as_mt) {
-                if (mt_launch(h, trial[0].v, AT_MT_TICKS, false)) failed[t] = true;
+                if (mt_launch(h, trial[0].v, AT_MT_TICKS, false, nullptr)) failed[t] = true;
             } else
             for (size_t l = 0; l < trial.size(); ++l) {           // every launch with the rows edges_impl gives it
                 LaunchCtx c;
@@ -1732,8 +1828,30 @@ static int launch_pending(fibhip_t h, int n)
 // launch the ticks fibhip_step left pending; every entry point that observes or changes the state calls this first
 static int flush(fibhip_t h)
 {
+    if (h->spec_n > 0) {
+        // The caller did not go on as predicted.  What it has been handed of the run-ahead (spec_used ticks) is recomputed
+        // from the state it started from — still intact: the launch wrote the other slab only — and the launch itself is
+        // told to stop at its next tick boundary (the cancel word, written through the second stream while it runs).
+        const int redo = h->spec_used;
+        if (h->epochs) {
+            unsigned one = 1u;
+            memcpy(h->probe_host + 9, &one, sizeof one);
+            HIPCHK(hipMemcpyAsync(h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE, h->probe_host + 9, sizeof one,
+                                  hipMemcpyHostToDevice, h->s1));
+            // whatever the main stream does next comes after that write (the launch it is meant for is already running there):
+            // the words are cleared again before the next multi-tick launch, and the write must not land after the clearing
+            HIPCHK(hipEventRecord(h->ev_int, h->s1));
+            HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
+            h->epochs_stale = true;
+        }
+        h->spec_n = h->spec_used = 0;
+        h->mt_run -= redo;
+        h->pending += redo;
+    }
     const int rc = launch_pending(h, h->pending);
+    h->series_fresh = h->mt_run > 0;
     if (h->mt_run > 0) {                            // the caller is about to look: the next tick starts a new series
+        h->mt_run_prev2 = h->mt_run_prev;
         h->mt_run_prev = h->mt_run;
         h->mt_run = 0;
     }
@@ -1773,6 +1891,20 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // every waiting tick, up to mt_max.  mt_cur is 1 after any call that observes the state, so the device starts at once;
     // then the rest of the series if the caller works in series of equal length (run() with an image() every n ticks, a
     // benchmark region: the ticks between the last two observations), else 2, 4, ... mt_max while the caller keeps stepping.
+    if (h->spec_n > 0 && nticks > 0) {                 // ticks that have been computed ahead already
+        const int take = imin(nticks, h->spec_n - h->spec_used);
+        h->spec_used += take;
+        h->mt_run += take;
+        nticks -= take;
+        if (h->spec_used == h->spec_n) {             // all handed out: the state moves to where the launch put it
+            memcpy(h->cur, h->spec_nxt, sizeof h->cur);
+            h->n_mt_launches++;
+            h->n_mt_ticks += h->spec_n;
+            h->n_ticks += h->spec_n;
+            h->spec_n = h->spec_used = 0;
+        }
+        if (nticks == 0) return 0;
+    }
     if (h->mt_max > 1 && nticks > 0 && !h->tracing) {
         if (int rc = check_ready(h)) return rc;
         if (!h->tuned)

@@ -424,10 +424,18 @@ __device__ unsigned long long fib_stamps[4096 * 16];
 struct MtArgs {
     float *xb;            // exchange buffer
     unsigned *epoch;      // one word per tile, MT_EPOCH_STRIDE words apart
-    unsigned *err;        // [0]: a tile gave up waiting
+    unsigned *err;        // [0]: a tile gave up waiting; [MT_EPOCH_STRIDE]: the host does not want this launch any more
     unsigned epoch0;      // value of every epoch word when the launch starts
     int nticks;           // ticks this launch advances
+    // read-back inside the launch (fibhip.hip `run-ahead`): every tile also writes array `snap_var` of the state the launch
+    // STARTS from into page-locked host memory during its first ticks and then raises its word in `snap_flag` (host memory
+    // too, 64 bytes apart) to `snap_seq` — the host has the frame while the launch is still computing
+    float *snap;
+    unsigned *snap_flag;
+    unsigned snap_seq;
+    int snap_var;
 };
+constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
 constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
 constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
 
@@ -504,6 +512,22 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #pragma unroll
         for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
         if (PHASE) pc[r].load(ph, oy * g.W + ox);                   // (the phase arrays are always planar)
+    }
+    if constexpr (MT) {
+        // read-back inside the launch: this tile's cells of one array of the state the launch starts from, straight into
+        // page-locked host memory, by system-scope (write-through) stores: plain stores stay in the L2 — frames came back with
+        // cells of the previous read-back — and the L2 write-back of a system-scope release fence in every tile at the same
+        // moment cost 15 us per launch.  They drain with everything else at the first tick boundary, where the tile's word is
+        // raised.  (Tried: the frame in three parts over three ticks — no faster, and the extra registers cost 2.7 %.)
+        if (mt.snap) {                                              // (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float x = s[r][0];
+#pragma unroll
+                for (int v = 1; v < NV; ++v) x = mt.snap_var == v ? s[r][v] : x;
+                if (own[r]) __hip_atomic_store(mt.snap + off[r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through
+            }
+        }
     }
     // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
     // the box reaches the domain edge on that side (no staleness enters through a real boundary)
@@ -636,23 +660,36 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave, before the barrier
         __syncthreads();
         const unsigned want = mt.epoch0 + (unsigned)tick + 1u;
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every wave's write-through stores to the host frame have been acknowledged (vmcnt(0) before the barrier above):
+            // the word follows them
+            if (tick == 0 && mt.snap) {
+                __hip_atomic_store(mt.snap_flag + (size_t)tile * MT_SNAP_STRIDE, mt.snap_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         // ---- wait for the eight neighbours (bounded) ---------------------------------------------------------
         if (wave == 0) {
             const int tiles_y = g.ntiles / g.tiles_x;
             const int d = lane < 4 ? lane : lane + 1;               // 0..8 without the centre
             const int ny = by + d / 3 - 1, nx = bx + d % 3 - 1;
             const bool need = lane < 8 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < g.tiles_x;
-            // lane 8 watches the give-up word instead
-            const unsigned *f = lane == 8 ? mt.err : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE;
+            // lane 8 watches the give-up word instead, lane 9 the host's cancel word (one line further: a launch that ran
+            // ahead of the caller and is not wanted any more, fibhip.hip `run-ahead`)
+            const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
+                                                                : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE);
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + MT_WAIT_TICKS;
             for (;;) {
                 const unsigned e = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool gave_up = __builtin_amdgcn_ballot_w64(lane == 8 && e != 0u) != 0ull;
+                const bool cancelled = __builtin_amdgcn_ballot_w64(lane == 9 && e != 0u) != 0ull;
                 // (epochs are compared as differences: they may wrap)
                 const bool ready = __builtin_amdgcn_ballot_w64(need && (int)(e - want) < 0) == 0ull;
-                if (ready && !gave_up) break;
+                if (ready && !gave_up && !cancelled) break;
+                if (cancelled) {                                    // not an error: the results are simply not wanted
+                    if (lane == 0) mt_abort = 1;
+                    break;
+                }
                 if (gave_up || __builtin_amdgcn_s_memrealtime() > t_end) {
                     if (lane == 0) {
                         __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -736,6 +736,120 @@ def test_br_multi_tick_launches_bit_identical(gpu_lib, monkeypatch, policy, cheb
         assert np.isfinite(x).all()
         assert np.array_equal(x, y), 'observation %d differs (max |d| %.3g)' % (i, float(np.abs(x - y).max()))
 
+
+@pytest.mark.parametrize('policy', POLICIES)
+def test_fenton_run_ahead_matches_one_launch_per_tick(gpu_lib, monkeypatch, policy):
+    """run-ahead: after two equally long series of ticks that each end in ONE read-back, the read-back launches the next
+    series before it waits for its copy, and fibhip_step hands those ticks out.  Whatever the caller does instead of
+    stepping on — a pace, a host write, a probe, an early or a late read-back, a sync — must see exactly what one launch
+    per tick (FIBHIP_MT=0) leaves: the ticks handed out so far are recomputed from the untouched state, the rest is
+    cancelled.  Also: in the steady pattern a series costs ONE launch."""
+    from fib_tf_amd import _lib
+    H, W = 130, 150
+    init, phi = _fenton_state(H, W, 31)
+    script = ([('steps', 10), ('get',)] * 4 +                                  # steady: run-ahead from the third read-back on
+              [('steps', 4), ('pace',), ('steps', 6), ('get',)] +              # a pace in the middle of a run-ahead series
+              [('steps', 10), ('get',), ('steps', 10), ('get',)] +
+              [('steps', 3), ('get',)] +                                       # an early read-back
+              [('steps', 10), ('get',), ('steps', 10), ('get',), ('get',)] +   # two read-backs in a row
+              [('steps', 15), ('get',)] +                                      # a longer series than predicted
+              [('steps', 10), ('get',), ('steps', 10), ('get',)] +
+              [('steps', 5), ('sync',), ('steps', 5), ('get',)] +
+              [('steps', 10), ('get',), ('steps', 10), ('get',)] +
+              [('steps', 2), ('set',), ('steps', 8), ('get',)] +
+              [('steps', 10), ('get',), ('steps', 10), ('get',)] +
+              [('steps', 7), ('probe',), ('steps', 3), ('get',), ('steps', 10), ('getall',)])
+
+    def play(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+        st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST if policy == 'fast' else 0)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        seen, steady = [], None
+        for k, op in enumerate(script):
+            if op[0] == 'steps':
+                for _ in range(op[1]):
+                    st.step(1)
+            elif op[0] == 'get':
+                seen.append(st.get_state(0).copy())
+            elif op[0] == 'getall':
+                seen.append(st.get_state(-1))
+            elif op[0] == 'pace':
+                st.pace(10, 40, 20, 60, 1.0, 0.0)
+            elif op[0] == 'sync':
+                st.sync()
+            elif op[0] == 'set':
+                st.set_state(2, (st.get_state(2) * np.float32(0.97)).astype(np.float32))
+            elif op[0] == 'probe':
+                seen.append(np.float32(st.probe(0, 64, 75)))
+            if k == 5:
+                steady = st.launch_stats()['launches']
+            if k == 7:
+                steady = st.launch_stats()['launches'] - steady        # launches of the fourth steady series
+        stats = st.launch_stats()
+        st.close()
+        return seen, steady, stats
+
+    a, steady, sa = play(True)
+    b, _, sb = play(False)
+    assert sa['ticks'] == sb['ticks'] == sum(op[1] for op in script if op[0] == 'steps')
+    assert steady == 1, 'a steady series should be one launch (the run-ahead), got %r' % steady
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), 'observation %d differs' % i
+
+
+def test_run_ahead_off_switch(gpu_lib, monkeypatch):
+    from fib_tf_amd import _lib
+    monkeypatch.setenv('FIBHIP_AHEAD', '0')
+    monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+    init, phi = _fenton_state(64, 64, 2)
+    st = _lib.Stepper(_lib.FENTON4V, 64, 64, 0.1, 1.3, flags=_lib.FAST)
+    st.set_state(-1, init)
+    for _ in range(4):
+        for _ in range(10):
+            st.step(1)
+        st.get_state(0)
+    l0 = st.launch_stats()['launches']
+    for _ in range(10):
+        st.step(1)
+    st.get_state(0)
+    assert st.launch_stats()['launches'] - l0 == 2          # the first tick at once, the other nine together; nothing ahead
+    st.close()
+
+
+@pytest.mark.parametrize('H,W,period', [(512, 512, 2), (200, 300, 3), (512, 512, 10)])
+def test_read_back_inside_the_launch_delivers_every_frame(gpu_lib, monkeypatch, H, W, period):
+    """the run-ahead launch writes the frame into the caller's page-locked array itself and raises one word per tile in host
+    memory; the host returns when every word has arrived.  A word that overtook its tile's cells would hand out a frame
+    with cells of the PREVIOUS read-back (the pinned arrays are reused): 400 frames, short series (the frame then changes
+    from read-back to read-back while the stores are still on their way), each compared with the plain path."""
+    from fib_tf_amd import _lib
+    monkeypatch.delenv('FIBHIP_MT', raising=False)
+    monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+    init, phi = _fenton_state(H, W, 77)
+    frames = {}
+    for ahead in ('1', '0'):
+        monkeypatch.setenv('FIBHIP_AHEAD', ahead)
+        st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        out = []
+        for k in range(400):
+            st.step(period)
+            out.append(st.get_state(k % 2 * 3).sum(dtype=np.float64))       # U and S alternately; the array is reused at once
+            if k % 97 == 0:
+                out.append(st.get_state(0).copy())
+        out.append(st.get_state(-1))
+        frames[ahead] = out
+        st.close()
+    for i, (x, y) in enumerate(zip(frames['1'], frames['0'])):
+        assert np.array_equal(x, y), 'read-back %d differs' % i
+
 @pytest.mark.parametrize('policy', POLICIES)
 def test_fenton_ragged_nophase(gpu_lib, golden, policy):
     from fib_tf_amd.fenton import Fenton4v
