@@ -388,8 +388,18 @@ __device__ unsigned long long fib_stamps[4096 * 16];
         if ((threadIdx.x & 63) == 0 && (slot) < 16)                                              \
             fib_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// (tools/ubench/stamp_mt.hip: the phases of a tick boundary inside a multi-tick launch; the last boundary's values stay)
+__device__ unsigned long long fib_bstamps[4096 * 16];
+#define FIB_BSTAMP(slot)                                                                         \
+    do {                                                                                         \
+        if ((threadIdx.x & 63) == 0)                                                             \
+            fib_bstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define FIB_BSTAMP_WAIT() __builtin_amdgcn_s_waitcnt(0x0070)      /* vmcnt(0) lgkmcnt(0): the phase's loads have landed */
 #else
 #define FIB_STAMP(slot) do { } while (0)
+#define FIB_BSTAMP(slot) do { } while (0)
+#define FIB_BSTAMP_WAIT() do { } while (0)
 #endif
 
 // strip_kernel<M,P,MODE,K,TX,TY,R,PHASE> — the K > 1 workhorse.
@@ -646,6 +656,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         const unsigned plane16 = (unsigned)(g.H * g.W) * 16u;       // bytes of one [H*W] array of 16-byte cells
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(mt.xb, 0, (int)(2u * NC4 * plane16), 0x00020000);
         const unsigned pbase = (unsigned)(tick & 1) * NC4 * plane16;
+        FIB_BSTAMP(0);
         // ---- publish the tile: 16-byte cells, write-through -------------------------------------------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -657,8 +668,11 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 }
             }
         }
+        FIB_BSTAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave, before the barrier
+        FIB_BSTAMP(2);
         __syncthreads();
+        FIB_BSTAMP(3);
         const unsigned want = mt.epoch0 + (unsigned)tick + 1u;
         if (threadIdx.x == 0) {
             __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -700,7 +714,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        FIB_BSTAMP(4);
         __syncthreads();
+        FIB_BSTAMP(5);
         if (mt_abort) return;                                       // whole workgroup: the results of this launch are void
         // ---- the rim of the compute box, from what the neighbours published ------------------------------
         // (every load of handed-over bytes is an sc1 load; a thread outside the box or the grid reads a clamped
@@ -732,6 +748,8 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             ring = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(pbase + (unsigned)((cy0 - 1) * g.W + cxx) * 16u), 0, 16));
         if (ring_bot)
             ring = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(pbase + (unsigned)((cy0 + CY) * g.W + cxx) * 16u), 0, 16));
+        FIB_BSTAMP_WAIT();
+        FIB_BSTAMP(6);
         // ---- the whole box's potential into the tile, as after a sub-step — plus the ring (columns 0 and 63 of the
         // tile, rows 0 and CY+1), which the sub-steps never write
         float *B0 = lds[0];
@@ -758,13 +776,17 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             if (ring_top) B0[(gx >= 1 && gx <= g.W - 2) ? lane : NL + 2 * LP + lane] = ring;
             if (ring_bot) B0[(gx >= 1 && gx <= g.W - 2) ? (CY + 1) * LP + lane : NL + 2 * LP + lane] = ring;
         }
+        FIB_BSTAMP(7);
         __syncthreads();
+        FIB_BSTAMP(8);
 #pragma unroll
         for (int q = 0; q < R + 2; ++q) {
             win[q][0] = B0[aW + q * LP];
             win[q][1] = B0[aC + q * LP];
             win[q][2] = B0[aE + q * LP];
         }
+        FIB_BSTAMP_WAIT();
+        FIB_BSTAMP(9);
     }
     }
 
