@@ -9,6 +9,8 @@
 //   mode 0  exchange buffer [2][H][W] of 16-byte cells, buffer_store/load_dwordx4 ... sc1, flag = sc1 store, sc1 poll
 //   mode 1  four planar arrays [2][4][H][W], global_store/load_dword ... sc1 (the slab's own layout)
 //   mode 2  planar arrays, plain stores + agent release fence / agent acquire fence + plain loads
+//   mode 3  the word travels WITH the data: 8-byte {tag, value} granules (32 bytes per cell, two dwordx4 sc1 stores), no
+//           drain, no epoch word, no barrier: every wave re-reads its rim cells until every tag says `this tick`
 //
 // build: hipcc -O3 --offload-arch=gfx950 handoff.hip -o handoff ;  run: ./handoff [ticks] [busy_cycles]
 #include <hip/hip_runtime.h>
@@ -66,6 +68,55 @@ handoff(unsigned *xbuf, unsigned *flags, unsigned *err, unsigned long long *cyc,
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, ts = 0;
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc[i] += n_ - ts; ts = n_; } while (0)
     for (int t = 0; t < T; ++t) {
+        if (MODE == 3) {
+            // ---- "compute" ----
+            if (busy > 0) {
+                const unsigned j = (unsigned)(tile * 2654435761u + t * 40503u) >> 22;
+                const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)busy + j;
+                while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(2);
+            }
+            const int par = t & 1;
+            const unsigned tag = (unsigned)(t + 1);
+            auto rs3 = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)(2 * plane * 32), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (own[r]) {
+                    const size_t cell = (size_t)gy[r] * W + gx;
+                    v4u a = {tag, expect(gy[r], gx, 0, t + 1), tag, expect(gy[r], gx, 1, t + 1)};
+                    v4u b = {tag, expect(gy[r], gx, 2, t + 1), tag, expect(gy[r], gx, 3, t + 1)};
+                    __builtin_amdgcn_raw_buffer_store_b128(a, rs3, (int)((par * plane + cell) * 32), 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(b, rs3, (int)((par * plane + cell) * 32 + 16), 0, 16);
+                }
+            }
+            if (t + 1 == T) break;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                unsigned wrong = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (rim[r]) {
+                        const size_t cell = (size_t)gy[r] * W + gx;
+                        const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rs3, (int)((par * plane + cell) * 32), 0, 16);
+                        const v4u b = __builtin_amdgcn_raw_buffer_load_b128(rs3, (int)((par * plane + cell) * 32 + 16), 0, 16);
+                        ok = ok && a.x == tag && a.z == tag && b.x == tag && b.z == tag;
+                        wrong += (a.y != expect(gy[r], gx, 0, t + 1)) + (a.w != expect(gy[r], gx, 1, t + 1)) +
+                                 (b.y != expect(gy[r], gx, 2, t + 1)) + (b.w != expect(gy[r], gx, 3, t + 1));
+                    }
+                }
+                if (__all(ok)) {
+                    bad += wrong;
+                    break;
+                }
+                if (++spins > (SPIN_MAX >> 6)) {
+                    if (lane == 0) atomicOr(err + 1, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();                                          // (the real kernel publishes the rim to LDS here)
+            continue;
+        }
         // ---- "compute" ----
         if (busy > 0) {
             const unsigned j = (unsigned)(tile * 2654435761u + t * 40503u) >> 22;      // 0..1023 cycles of jitter
@@ -206,11 +257,11 @@ int main(int argc, char **argv)
     const int T = argc > 1 ? atoi(argv[1]) : 200;
     unsigned *xbuf, *flags, *err;
     unsigned long long *cyc;
-    CK(hipMalloc((void **)&xbuf, 2ull * H * W * 16));
+    CK(hipMalloc((void **)&xbuf, 2ull * H * W * 32));
     CK(hipMalloc((void **)&flags, (size_t)NTILES * 1024 * sizeof(unsigned)));
     CK(hipMalloc((void **)&err, 2 * sizeof(unsigned)));
     CK(hipMalloc((void **)&cyc, 2 * NTILES * 8 * sizeof(unsigned long long)));
-    CK(hipMemset(xbuf, 0xff, 2ull * H * W * 16));
+    CK(hipMemset(xbuf, 0xff, 2ull * H * W * 32));
     const int busys[] = {0, 24000};
     const int strides[] = {1, 32, 64, 1024};
     for (int b : busys) {
@@ -221,6 +272,8 @@ int main(int argc, char **argv)
             run<1>("planar arrays, dword sc1", T, b, fs, xbuf, flags, err, cyc);
         }
         run<2>("planar arrays, plain + release/acquire fences", T, b, 1024, xbuf, flags, err, cyc);
+        CK(hipMemset(xbuf, 0xff, 2ull * H * W * 32));
+        run<3>("8-byte {tag, value} granules, no word, no drain", T, b, 1, xbuf, flags, err, cyc);
     }
     // the launch boundary this replaces: T launches of one tick each
     {
