@@ -178,7 +178,7 @@ static hipError_t launch_pointwise(hipStream_t st, const LaunchCtx &c)
 // One launcher for every kernel of a run-time module (a traced model compiled in-process by hiprtc): the same grids
 // as launch_tick / launch_strip / launch_pointwise, the kernel arguments laid out by hand as the compiler lays out
 // (Geo, PtrTab<NVAR>, PhaseTab, Consts, int) — every argument at its natural alignment, in order.
-enum { MK_TICK = 0, MK_STRIP = 1, MK_POINTWISE = 2 };
+enum { MK_TICK = 0, MK_STRIP = 1, MK_POINTWISE = 2, MK_STRIP_MT = 3 };
 static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
 {
     Geo g = c.g;
@@ -196,8 +196,9 @@ static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
         if (g.ntiles <= 0) return hipSuccess;
         threads = c.kind == MK_TICK ? c.NT : 64 * ((c.TY + 2 * (c.K - 1) + (-c.NT) - 1) / (-c.NT));
         grid = ((g.ntiles + 7) / 8) * 8;
+        if (c.kind == MK_STRIP_MT) g.ntiles = g.tiles_x * g.ty_a;       // (one band: the whole, unsharded grid)
     }
-    alignas(8) char buf[sizeof(Geo) + 8 + 2 * FIB_MAXVAR * sizeof(void *) + sizeof(PhaseTab) + 64 + 16];
+    alignas(8) char buf[sizeof(Geo) + 8 + 2 * FIB_MAXVAR * sizeof(void *) + sizeof(PhaseTab) + 64 + 16 + sizeof(MtArgs) + 8];
     size_t off = 0;
     auto put = [&](const void *p, size_t n, size_t align) {
         off = (off + align - 1) & ~(align - 1);
@@ -214,6 +215,7 @@ static hipError_t launch_module(hipStream_t st, const LaunchCtx &c)
     const char zeros[64] = {0};
     if (c.consts_bytes > 0) put(c.consts ? c.consts : zeros, (size_t)c.consts_bytes, 4);
     if (c.kind != MK_POINTWISE) put(&c.sub0, sizeof c.sub0, alignof(int));
+    if (c.kind == MK_STRIP_MT) put(&c.mt, sizeof c.mt, alignof(MtArgs));      // strip_mt_kernel's last argument
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &off, HIP_LAUNCH_PARAM_END};
     return hipModuleLaunchKernel(c.kern, grid, 1, 1, threads, 1, 1, 0, st, nullptr, config);
 }
@@ -228,6 +230,7 @@ struct Variant {
     hipFunction_t kern = nullptr;   // run-time module kernels only (fn == launch_module)
     int kind = 0;
     launch_fn fn_mt = nullptr;      // the same shape advancing several ticks per launch (strip_mt_kernel), or null
+    hipFunction_t kern_mt = nullptr;        // ... of a run-time module (fn_mt == launch_module, kind MK_STRIP_MT)
 };
 
 #define V4(MODEL, MID, MODE, K, TX, TY, NT)                                                        \
@@ -908,7 +911,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         // FIBHIP_MT=0 switches multi-tick launches off, FIBHIP_MT_MAX bounds the ticks of one launch
         const char *e = getenv("FIBHIP_MT"), *em = getenv("FIBHIP_MT_MAX");
         h->mt_max = (e && atoi(e) == 0) ? 1 : (em && atoi(em) > 0 ? atoi(em) : MT_MAX_TICKS);
-        if (nv % 4 != 0 || interleaved || desc->ghost_top || desc->ghost_bottom || mod || (long long)h->cells * nv * 8 >= (1LL << 31))
+        if (interleaved || desc->ghost_top || desc->ghost_bottom || (long long)h->cells * ((nv + 3) / 4 * 4) * 8 >= (1LL << 31))
             h->mt_max = 1;
     }
     h->agg = nullptr;
@@ -1437,7 +1440,7 @@ static void mt_forget(fibhip_ctx *h)
 static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_out, float *snap, int snap_var)
 {
     if (!h->xbuf) {
-        if (hipMalloc((void **)&h->xbuf, 2 * (size_t)h->nvar * h->cells * sizeof(float)) != hipSuccess) {
+        if (hipMalloc((void **)&h->xbuf, 2 * (size_t)((h->nvar + 3) / 4 * 4) * h->cells * sizeof(float)) != hipSuccess) {
             h->xbuf = nullptr;
             return fail(FIBHIP_ENOMEM, "hipMalloc of the tick-exchange buffer failed");
         }
@@ -1463,6 +1466,13 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
     c.mt.epoch0 = h->epoch_base;
     c.mt.nticks = T;
+    if (v->kern_mt) {                                 // a kernel of a run-time module (launch_module lays the arguments out)
+        c.kern = v->kern_mt;
+        c.kind = MK_STRIP_MT;
+        c.K = v->K; c.TX = v->TX; c.TY = v->TY; c.NT = v->NT;
+        c.nvar = h->nvar;
+        c.consts_bytes = h->mod ? h->mod->consts_bytes : 0;
+    }
     c.mt.snap = snap;
     c.mt.snap_flag = h->snap_flags;
     c.mt.snap_seq = h->snap_seq;
@@ -2384,6 +2394,21 @@ extern "C" int fibhip_module_load(int device, const void *code, size_t nbytes, c
         v.K = k.K; v.TX = k.TX; v.TY = k.TY; v.NT = k.NT;
         v.fn = launch_module;
         v.kind = k.kind;
+        if (k.kind == MK_STRIP_MT) {                    // the multi-tick form of a strip kernel listed before it
+            Variant *base = nullptr;
+            for (Variant &b : m->variants)
+                if (b.kind == MK_STRIP && b.mode == k.mode && b.fast == k.fast && b.phase == k.phase && b.K == k.K && b.TX == k.TX &&
+                    b.TY == k.TY && b.NT == k.NT)
+                    base = &b;
+            if (!base || !k.symbol || hipModuleGetFunction(&base->kern_mt, m->mod, k.symbol) != hipSuccess) {
+                hipModuleUnload(m->mod);
+                delete m;
+                return fail(FIBHIP_EINVAL, "module_load: kernel %d (%s): no strip kernel of that shape before it, or missing from the code object", i,
+                            k.symbol ? k.symbol : "(null)");
+            }
+            base->fn_mt = launch_module;
+            continue;
+        }
         const bool ok_shape = k.kind == MK_POINTWISE ||
                               (k.kind == MK_TICK && k.NT >= 64 && k.NT <= 1024 && k.K >= 1 && k.TX >= 1 && k.TY >= 1) ||
                               (k.kind == MK_STRIP && k.NT < 0 && k.NT > -32 && k.K >= 2 && k.TX + 2 * (k.K - 1) <= 62 &&

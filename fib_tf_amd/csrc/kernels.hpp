@@ -460,8 +460,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr int NV = M::NVAR;
     constexpr int CX = TX + 2 * (K - 1), CY = TY + 2 * (K - 1);
     static_assert(CX <= 62 && K > 1, "strip_kernel: compute box must fit 62 lanes");
-    static_assert(!MT || (CX == 62 && NV % 4 == 0 && TX >= K && TY >= K),
-                  "multi-tick launches: 62-column box, 16-byte cells, the rim inside the eight neighbours");
+    static_assert(!MT || (CX == 62 && TX >= K && TY >= K), "multi-tick launches: 62-column box, the rim inside the eight neighbours");
     constexpr int NW = (CY + R - 1) / R;
     constexpr int LP = 64, LQ = NW * R + 2, NL = LP * LQ;
     constexpr unsigned WMASK = M::mask(MODE);
@@ -652,7 +651,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 
     // ================= between two ticks of one launch =================
     if constexpr (MT) {
-        constexpr int NC4 = NV / 4;
+        constexpr int NC4 = (NV + 3) / 4;                           // 16-byte cells per grid cell (the last one padded)
         const unsigned plane16 = (unsigned)(g.H * g.W) * 16u;       // bytes of one [H*W] array of 16-byte cells
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(mt.xb, 0, (int)(2u * NC4 * plane16), 0x00020000);
         const unsigned pbase = (unsigned)(tick & 1) * NC4 * plane16;
@@ -663,7 +662,10 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             if (own[r]) {
 #pragma unroll
                 for (int c = 0; c < NC4; ++c) {
-                    const fib_v4f v = {s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]};
+                    // (a model whose arrays are not a multiple of four pads its last cell: the index is folded after unrolling)
+                    const int i1 = 4 * c + 1 < NV ? 4 * c + 1 : NV - 1, i2 = 4 * c + 2 < NV ? 4 * c + 2 : NV - 1,
+                              i3 = 4 * c + 3 < NV ? 4 * c + 3 : NV - 1;
+                    const fib_v4f v = {s[r][4 * c], s[r][i1], s[r][i2], s[r][i3]};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fib_v4u, v), rs, (int)(pbase + c * plane16 + (unsigned)off[r] * 16u), 0, 16);
                 }
             }
@@ -731,9 +733,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                     const fib_v4f v = __builtin_bit_cast(
                         fib_v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(pbase + c * plane16 + (unsigned)off[r] * 16u), 0, 16));
                     s[r][4 * c] = v.x;
-                    s[r][4 * c + 1] = v.y;
-                    s[r][4 * c + 2] = v.z;
-                    s[r][4 * c + 3] = v.w;
+                    if (4 * c + 1 < NV) s[r][4 * c + 1 < NV ? 4 * c + 1 : 0] = v.y;
+                    if (4 * c + 2 < NV) s[r][4 * c + 2 < NV ? 4 * c + 2 : 0] = v.z;
+                    if (4 * c + 3 < NV) s[r][4 * c + 3 < NV ? 4 * c + 3 : 0] = v.w;
                 }
             }
         }

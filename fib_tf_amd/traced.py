@@ -991,6 +991,11 @@ def _module_kernels(facts):
                 fn = 'tick_kernel' if kind == 0 else 'strip_kernel'
                 expr = 'fib::%s<fib::Custom, %s, 0, %d, %d, %d, %d, %s>' % (fn, pol, K, TX, TY, NT if kind == 0 else -NT, ph)
                 out.append((expr, {'kind': kind, 'mode': 0, 'fast': fast, 'phase': phase, 'K': K, 'TX': TX, 'TY': TY, 'NT': NT}))
+                # a strip that fuses the WHOLE tick also exists as the multi-tick launch (kind 3, listed right behind its
+                # strip kernel): up to 32 ticks per launch on grids whose tiles are all resident at once (csrc/kernels.hpp)
+                if kind == 1 and K == facts['spt'] and TX + 2 * (K - 1) == 62 and TX >= K and TY >= K:
+                    expr = 'fib::strip_mt_kernel<fib::Custom, %s, 0, %d, %d, %d, %d, %s>' % (pol, K, TX, TY, -NT, ph)
+                    out.append((expr, {'kind': 3, 'mode': 0, 'fast': fast, 'phase': phase, 'K': K, 'TX': TX, 'TY': TY, 'NT': NT}))
         for mode in range(1, facts['nmodes']):
             expr = 'fib::pointwise_kernel<fib::Custom, %s, %d>' % (pol, mode)
             out.append((expr, {'kind': 2, 'mode': mode, 'fast': fast, 'phase': 0, 'K': 1, 'TX': 0, 'TY': 0, 'NT': 0}))

@@ -201,6 +201,35 @@ def test_fusion_depth_does_not_change_a_bit(gpu_lib, name, policy, monkeypatch):
     assert np.array_equal(a, b)
 
 
+
+@pytest.mark.parametrize('name', ['ap', 'fv', 'ev', 'mrfhn'])
+@pytest.mark.parametrize('policy', ['exact', 'fast'])
+def test_generated_kernels_run_several_ticks_per_launch(gpu_lib, name, policy, monkeypatch):
+    """a traced model's tick-fusing strip kernel also exists as the multi-tick launch (kind 3 of its run-time module):
+    up to 32 ticks per launch with the tiles handing their rims to each other, on arrays of 2 (padded 16-byte cell), 4
+    and 8 variables — bitwise equal to one launch per tick (FIBHIP_MT=0), with a pace and read-backs in between"""
+    def run(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        monkeypatch.setenv('FIBHIP_AUTOTUNE', '0')              # the header's own plan: the tick-fusing strip
+        m = make_model(name, 96, 130, (40, 50, 9), fast_math=(policy == 'fast'))
+        m.define()
+        state, _ = drive(m, name, 23, 7)                        # run(): single-tick calls -> launches of 1, 2, 4, ... ticks
+        st = m._stepper
+        st.step(37)                                             # one call of many ticks: a 32-tick launch + the rest
+        out = [state, st.get_state(0).copy()]
+        st.step(5)
+        out.append(st.get_state(-1))
+        return out, st.ticks_per_launch(), st.launch_plan()
+    (a, tpl, plan), (b, _, _) = run(True), run(False)
+    if plan[1] == 1 and plan[0] > 1:
+        assert tpl > 1, 'the multi-tick form of the generated strip kernel was not used (plan %r)' % (plan,)
+    for x, y in zip(a, b):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
+
+
 def test_traced_model_errors_are_loud(gpu_lib):
     """what the tracer cannot compile it refuses by name — there is no fallback path"""
     import fib_tf_amd.tfgraph as tf
