@@ -1141,8 +1141,8 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
     // Run-ahead.  A caller that alternates series of n ticks with one read-back — IonicModel.run() with image() every n
     // ticks, fenton.py:184-185 — would leave the device idle for the whole read-back (34 us of a 125 us series at
-    // 512x512).  When the last two series were equally long, the next n ticks are launched HERE, before the copy is waited
-    // for: the copy runs on the second stream from the slab the launch only reads.  fibhip_step then hands those ticks out
+    // 512x512).  When the last two series were equally long, the next n ticks are launched HERE, before the frame is waited
+    // for (the launch reads the slab the frame comes from and writes the other one).  fibhip_step then hands those ticks out
     // without launching anything; any other call first makes the state what the caller has been told it is (flush()).
     // The frame itself travels INSIDE that launch when the destination is page-locked memory the device can write
     // (fibhip_host_alloc: what the Python binding hands in): every tile stores its cells of the array straight into it
