@@ -120,7 +120,12 @@ int fibhip_set_state(fibhip_t h, int var, const float *src);
 int fibhip_get_state(fibhip_t h, int var, float *dst);
 /* The same read-back without the staging copy: `dst` should be page-locked memory from fibhip_host_alloc (the Python
  * binding keeps a small pool of such buffers behind the arrays `eval()` / `image()` return: the reference driver reads
- * the potential back 100 times per simulated second, fenton.py:184-185).                                            */
+ * the potential back 100 times per simulated second, fenton.py:184-185).
+ * Run-ahead: when the caller's last two series of ticks were equally long and each ended in one read-back of one array
+ * (that very driver), this call launches the NEXT series before it returns — the frame then travels inside that launch
+ * (the device writes `dst` itself) — and fibhip_step hands those ticks out without launching; any other call on the
+ * handle first restores exactly the state the caller has been told about (ticks recomputed, the rest cancelled).
+ * Invisible except in time; FIBHIP_AHEAD=0 switches it off.                                                          */
 int fibhip_get_state_direct(fibhip_t h, int var, float *dst);
 int fibhip_host_alloc(size_t nbytes, void **out);
 int fibhip_host_free(void *p);
@@ -130,9 +135,11 @@ int fibhip_host_free(void *p);
  * (br.py:223-240).                                                                                      */
 int fibhip_set_consts(fibhip_t h, const float *tbl, int n);
 
-/* == nticks x sess.run(self._ode_op) (ionic.py:202-203).  Asynchronous.  The library may hold the LAST tick
- * of the call back until the next call on the handle (any call launches it; fibhip_step_slow fuses with it):
- * invisible to the caller except that work is enqueued one call later.                                     */
+/* == nticks x sess.run(self._ode_op) (ionic.py:202-203).  Asynchronous: an ENQUEUE.  The library may hold ticks back
+ * until a launch is worth issuing — the last tick of a call (fibhip_step_slow fuses with it), up to three ticks
+ * (Courtemanche, fast policy) or up to 32 (Fenton / Beeler-Reuter on grids whose tiles are all resident at once: one
+ * launch loops over them, see fibhip_ticks_per_launch) — and any call on the handle that observes or changes the state
+ * launches what is held first: invisible to the caller except that work may be enqueued a few calls later.        */
 int fibhip_step(fibhip_t h, int nticks);
 
 /* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and

@@ -31,6 +31,25 @@ def test_library_exports_every_declared_symbol():
     assert L.fibhip_nvar(7) < 0 and b'unknown model' in L.fibhip_last_error()
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden: every exported FUNCTION is an entry point of include/fibhip.h (no kernel host stub, no template
+    instance of the library's own code; what the C++ runtime's containers leave as weak symbols aside), and a non-stock build
+    (the Beeler-Reuter table baked in) names none of its kernels like the stock library does (FIB_BUILD_TAG)"""
+    import glob
+    from fib_tf_amd import _lib
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.SO]).decode()
+    funcs = [l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in 'TW']
+    # (the implicit destructor of the ABI's own opaque handle type, `fibhip_ctx`, is exported with the type)
+    foreign = [f for f in funcs if 'fibhip_' not in f and not f.startswith('_ZNSt') and f not in ('_init', '_fini')]
+    assert not foreign, foreign[:5]
+    assert not [f for f in funcs if '__device_stub__' in f]
+    kernels = {l.split()[-1] for l in out.splitlines() if '_kernel' in l}
+    for spec in glob.glob(os.path.join(os.path.dirname(_lib.SO), '_spec', 'libfibhip_br_*.so')):
+        o2 = subprocess.check_output(['nm', '-D', '--defined-only', spec]).decode()
+        k2 = {l.split()[-1] for l in o2.splitlines() if '_kernel' in l}
+        assert k2 and not (k2 & kernels), sorted(k2 & kernels)[:3]
+
+
 def test_desc_layout_matches_header():
     """ctypes mirror of fibhip_desc: field order/types must follow include/fibhip.h"""
     from fib_tf_amd import _lib
