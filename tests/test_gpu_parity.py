@@ -1423,6 +1423,7 @@ def test_readback_into_page_locked_arrays(gpu_lib):
     pageable memory"""
     import gc
     from fib_tf_amd import _lib
+    gc.collect()                       # page-locked arrays of earlier tests that only the collector can free leave the pool first
     rng = np.random.default_rng(3)
     H, W = 37, 53
     init = rng.uniform(0, 1, (4, H, W)).astype(np.float32)
