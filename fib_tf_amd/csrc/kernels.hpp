@@ -571,8 +571,57 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #define FIB_STEP_UNROLL 2
 #endif
     constexpr int STEP_UNROLL = FIB_STEP_UNROLL;
+    // A strip that stays whole for all K sub-steps — no row of it goes stale inside the tick, none is a border or a
+    // ghost-source row of the grid (more than half of a tile's strips, and the ones that carry its own cells) — runs the
+    // step loop without any of the row bookkeeping: ~35 scalar instructions and a dozen branches fewer per sub-step.
+    // Only in the multi-tick kernel: the second copy of the step loop costs ~30 registers, which a grid with several
+    // workgroups per compute unit pays with its occupancy (measured with the specialisation in every strip kernel: 512x512
+    // multi-tick 12.53 -> 11.93 us per tick, but 4096x4096 388 -> 627 us and 1024x1024 35.0 -> 38.3); multi-tick grids have
+    // at most one workgroup per compute unit by construction.
+    // (and only where the registers are there: at 16 waves per workgroup the budget is 128; four-row strips and Beeler-Reuter's
+    // 16-wave shape spilled with the second loop and keep one)
+    constexpr bool WHOLE_LOOP = MT && R <= 3 && (NV * R <= 16 || NW <= 15);
+    const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
+                       pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
 #pragma unroll 1
     for (int tick = 0;; ++tick) {
+    if (WHOLE_LOOP && whole) {
+#pragma unroll STEP_UNROLL
+        for (int st = 0; st < K; ++st) {
+            float *B = lds[(st & 1) ^ 1];
+            float lp[R], cc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
+                                  win[r][2], win[r + 2][2], win[r + 1][1]);
+                if (PHASE) l = pc[r].add(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2]);
+                lp[r] = l;
+                cc[r] = win[r + 1][1];
+            }
+            if constexpr (M::HAS_VEC) {
+                M::template stepN<P, MODE, R>(s, cc, lp, kk, sub0 + st);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) M::template step<P, MODE>(s[r], cc[r], lp[r], kk, sub0 + st);
+            }
+            if (st + 1 < K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) B[wi + r * LP] = s[r][0];
+#ifndef FIB_DIAG_NO_BARRIER
+                __syncthreads();
+#endif
+#ifndef FIB_DIAG_NO_RELOAD
+#pragma unroll
+                for (int q = 0; q < R + 2; ++q) {
+                    win[q][0] = B[aW + q * LP];
+                    win[q][1] = B[aC + q * LP];
+                    win[q][2] = B[aE + q * LP];
+                }
+#endif
+            }
+            FIB_STAMP(3 + st);
+        }
+    } else {
 #pragma unroll STEP_UNROLL
     for (int st = 0; st < K; ++st) {
         float *B = lds[(st & 1) ^ 1];
@@ -646,6 +695,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #endif
         }
         FIB_STAMP(3 + st);
+    }
     }
     if (!MT || tick + 1 >= mt.nticks) break;
 
