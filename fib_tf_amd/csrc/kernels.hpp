@@ -578,9 +578,10 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // workgroups per compute unit pays with its occupancy (measured with the specialisation in every strip kernel: 512x512
     // multi-tick 12.53 -> 11.93 us per tick, but 4096x4096 388 -> 627 us and 1024x1024 35.0 -> 38.3); multi-tick grids have
     // at most one workgroup per compute unit by construction.
-    // (and only where the registers are there: at 16 waves per workgroup the budget is 128; four-row strips and Beeler-Reuter's
-    // 16-wave shape spilled with the second loop and keep one)
-    constexpr bool WHOLE_LOOP = MT && R <= 3 && (NV * R <= 16 || NW <= 15);
+    // (and only where the registers are there and the bookkeeping is a visible share of the sub-step: four-row strips spilled
+    // with the second loop — at 16 waves per workgroup the budget is 128 registers — and Beeler-Reuter's eight arrays with ~270
+    // instructions per cell ran 1.5-3 % slower with it; both keep one loop)
+    constexpr bool WHOLE_LOOP = MT && NV * R <= 12;
     const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
 #pragma unroll 1
