@@ -466,6 +466,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr unsigned WMASK = M::mask(MODE);
     __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
+    __shared__ float snapl[MT ? NW * R * 64 : 1];                    // multi-tick launches: the frame's values, parked for one tick
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;
@@ -522,19 +523,24 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         for (int v = 0; v < NV; ++v) s[r][v] = pt.in[v][off[r]];
         if (PHASE) pc[r].load(ph, oy * g.W + ox);                   // (the phase arrays are always planar)
     }
+    // read-back inside the launch: this tile's cells of one array of the state the launch STARTS from go straight into
+    // page-locked host memory, by system-scope (write-through) stores: plain stores stay in the L2 — frames came back with
+    // cells of the previous read-back — and the L2 write-back of a system-scope release fence in every tile at the same
+    // moment cost 15 us per launch.  The values are taken here; the stores are issued at the start of the SECOND tick and the
+    // tile's word is raised at the boundary after it: issued here they had to drain at the first boundary together with the
+    // tile's exchange stores, and a 1 MiB frame of PCIe writes kept every tile waiting ~10 us there.  (Launches of two ticks
+    // have one boundary: stores here, word there.  Tried: the frame in three parts over three ticks, values re-read from the
+    // slab — no faster, and the extra registers cost 2.7 %.)
+    // (parked in LDS meanwhile: in registers they pushed the kernel to its 128-register budget and into scratch)
+    const int snap_at = (MT && mt.snap) ? (mt.nticks >= 3 ? 1 : 0) : -1;
     if constexpr (MT) {
-        // read-back inside the launch: this tile's cells of one array of the state the launch starts from, straight into
-        // page-locked host memory, by system-scope (write-through) stores: plain stores stay in the L2 — frames came back with
-        // cells of the previous read-back — and the L2 write-back of a system-scope release fence in every tile at the same
-        // moment cost 15 us per launch.  They drain with everything else at the first tick boundary, where the tile's word is
-        // raised.  (Tried: the frame in three parts over three ticks — no faster, and the extra registers cost 2.7 %.)
         if (mt.snap) {                                              // (wave-uniform)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float x = s[r][0];
 #pragma unroll
                 for (int v = 1; v < NV; ++v) x = mt.snap_var == v ? s[r][v] : x;
-                if (own[r]) __hip_atomic_store(mt.snap + off[r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through
+                snapl[(c0 + r) * 64 + lane] = x;                    // (read back by the same thread: no barrier needed)
             }
         }
     }
@@ -586,6 +592,13 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
 #pragma unroll 1
     for (int tick = 0;; ++tick) {
+    if constexpr (MT) {
+        if (tick == snap_at) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (own[r]) __hip_atomic_store(mt.snap + off[r], snapl[(c0 + r) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through
+        }
+    }
     if (WHOLE_LOOP && whole) {
 #pragma unroll STEP_UNROLL
         for (int st = 0; st < K; ++st) {
@@ -731,7 +744,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // every wave's write-through stores to the host frame have been acknowledged (vmcnt(0) before the barrier above):
             // the word follows them
-            if (tick == 0 && mt.snap) {
+            if (tick == snap_at) {
                 __hip_atomic_store(mt.snap_flag + (size_t)tile * MT_SNAP_STRIDE, mt.snap_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
