@@ -358,8 +358,8 @@ def measure_single(args, exact, with_extras, snapshots=None):
                         tile=(tw, th, tr), ticks_per_launch=max(1, nt // max(1, launches)) if multi else 1)
     if snapshots:
         m.image()                                     # set-up: the pinned staging buffer of the read-backs
-        ws = timed_regions(advance, st.sync, args.steps, 1, snap=True)
-        snaps = cells * args.steps * spt / ws[0] / 1e6
+        ws = timed_regions(advance, st.sync, args.steps, args.repeats, snap=True)     # regions and median like `value`
+        snaps = cells * args.steps * spt / statistics.median(ws) / 1e6
     return value, wall * 1000.0 / args.steps, roof, walls, snaps, m
 
 
@@ -426,8 +426,9 @@ def bench_single(args):
         'repeats': args.repeats, 'wall_ms_per_region': [round(w * 1e3, 4) for w in walls],
         'roofline': roof,
         'value_with_snapshots': None if snaps is None else round(snaps, 1),
-        'snapshots_note': 'same %d ticks with the reference driver\'s read-backs inside the timed region: image() (D2H of '
-                          'the potential) every 10 ms of simulated time (fenton.py:184-185)' % args.steps,
+        'snapshots_note': 'median of %d regions of the same %d ticks with the reference driver\'s read-backs inside the timed '
+                          'region: image() (the potential, into page-locked memory) every 10 ms of simulated time '
+                          '(fenton.py:184-185)' % (args.repeats, args.steps),
     }
     try:                                              # achievable-bandwidth yardstick, measured in this very run
         from fib_tf_amd import _lib
