@@ -254,19 +254,23 @@ def driver_loop(m, st, s2, court):
     return advance
 
 
-def timed_regions(advance, sync, steps, repeats, barrier=None, snap=False):
-    """`repeats` regions of exactly `steps` ticks, each bracketed by barrier + device sync; wall seconds per region"""
+def timed_regions(advance, sync, steps, repeats, barrier=None, snap=False, launches=None):
+    """`repeats` regions of exactly `steps` ticks, each bracketed by barrier + device sync; wall seconds per region
+    (`launches`: a callable counting kernel launches so far; its increments per region are appended to `launches.log`)"""
     walls = []
     for _ in range(repeats):
         sync()
         if barrier:
             barrier()
+        l0 = launches() if launches else 0
         t0 = time.perf_counter()
         advance(steps, snap)
         sync()
         if barrier:
             barrier()
         walls.append(time.perf_counter() - t0)
+        if launches:
+            launches.log.append(launches() - l0)
     return walls
 
 
@@ -275,10 +279,10 @@ def kernel_key(args, exact, H, W, fused, shard=False, ticks=1):
                                    ticks if ticks > 1 else fused, '/shard' if shard else '')
 
 
-def measure_single(args, exact, with_extras, snapshots=None):
-    """one model on device 0: (value, ms_per_tick, roofline dict, walls, snapshots value, model)"""
+def measure_single(args, exact, with_extras, snapshots=None, height=None, device=0):
+    """one model on one device: (value, ms_per_tick, roofline dict, walls, snapshots value, model)"""
     snapshots = with_extras if snapshots is None else snapshots
-    m, (loc, amp, s2_ms) = make_model(args, device=0, exact=exact)
+    m, (loc, amp, s2_ms) = make_model(args, height=height, device=device, exact=exact)
     m.define()
     m.add_pace_op('s2', loc, amp)
     s2 = m.millisecond_to_step(s2_ms)
@@ -298,8 +302,12 @@ def measure_single(args, exact, with_extras, snapshots=None):
     gc.freeze()
     advance(args.setup)                               # set-up: clocks and caches in their steady state
     advance(args.warmup)
-    walls = timed_regions(advance, st.sync, args.steps, args.repeats)
+    def nlaunch():
+        return st.launch_stats()['launches']
+    nlaunch.log = []
+    walls = timed_regions(advance, st.sync, args.steps, args.repeats, launches=nlaunch)
     wall = statistics.median(walls)
+    m._launches_per_region = nlaunch.log
     cells = m.height * m.width
     value = cells * args.steps * spt / wall / 1e6
 
@@ -424,6 +432,7 @@ def bench_single(args):
                    'parallelism': 'single device', 'setup_ticks': args.setup + 1,
                    'timing': 'median of %d regions of %d ticks' % (args.repeats, args.steps)},
         'repeats': args.repeats, 'wall_ms_per_region': [round(w * 1e3, 4) for w in walls],
+        'launches_per_region': getattr(m, '_launches_per_region', None),
         'roofline': roof,
         'value_with_snapshots': None if snaps is None else round(snaps, 1),
         'snapshots_note': 'median of %d regions of the same %d ticks with the reference driver\'s read-backs inside the timed '
@@ -669,6 +678,24 @@ def bench_ranks(args):
         st.eng.st.comm_free()
     dist.barrier()
     dist.destroy_process_group()
+    if out is not None and not args.no_single_leg:
+        # rank 0, after the group is gone (the other ranks have left): the SAME grid on this one device, timed like the N = 1
+        # line times its workload — the denominator a scaling figure of this series needs (the N = 1 line of bench.py is
+        # BASELINE configs[1], another grid)
+        import copy
+        try:
+            st.close()
+            a = copy.copy(args)
+            a.steps, a.setup, a.warmup, a.repeats = max(10, min(args.steps, 100)), 30, 10, 3
+            v1, ms1, roof1, _, _, m1 = measure_single(a, args.exact, False, snapshots=False, height=H, device=local)
+            out['single_device_same_grid'] = {
+                'value': round(v1, 1), 'unit': 'Mcell-steps/s', 'ms_per_step': round(ms1, 6), 'steps': a.steps,
+                'plan': plan_text(m1._stepper), 'roofline_frac': roof1['frac'],
+                'note': 'the whole %dx%d grid as ONE handle on rank 0\'s device, median of 3 regions of %d ticks, measured in '
+                        'this run after the ranks had finished' % (H, m1.width, a.steps)}
+            m1._stepper.close()
+        except Exception as e:                          # never lose the result line over the side leg
+            out['single_device_same_grid'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if out is not None and not args.no_cpu:             # rank 0, after the group is gone: the other ranks have left
         out['cpu_baseline'] = cpu_baseline(args, height=H, seconds=8.0)
     return out
@@ -680,7 +707,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5000, help='ticks timed per region (1 tick = dt_per_step sub-steps)')
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps ticks; the median is reported')
-    ap.add_argument('--setup', type=int, default=400, help='untimed set-up ticks before the warm-up (clocks, caches)')
+    ap.add_argument('--setup', type=int, default=4000, help='untimed set-up ticks before the warm-up: 50 ms at 512x512, the time the '
+                    'shader clock takes to settle after idling (400 ticks left a tick 3-4 %% slower: 12.3 vs 11.95 us)')
     ap.add_argument('--model', default='fenton', choices=['fenton', 'br', 'court'])
     ap.add_argument('--size', type=int, default=0, help='grid width (and height unless --scaling weak); default: 512 at '
                                                         'N=1 (1024 court), 4096 at N>1 (512 with --scaling weak)')
@@ -694,6 +722,7 @@ def main():
     ap.add_argument('--no-cheby', action='store_true')
     ap.add_argument('--skip', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-single-leg', action='store_true', help='N>1: skip the one-device run of the same grid on rank 0')
     ap.add_argument('--no-config-legs', action='store_true', help="N=1: skip the `configs` legs (BASELINE's other single-GPU configurations)")
     ap.add_argument('--halo-ticks', type=int, default=0, help='N > 1: ticks between two halo exchanges (ghost zone depth); 0 = '
                     'chosen from the block height (at most 4, extra rows within half of the block)')

@@ -156,6 +156,7 @@ SYMBOLS = {
     'fibhip_host_free': ([C.c_void_p], C.c_int),
     'fibhip_ticks_per_launch': ([_h], C.c_int),
     'fibhip_launch_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
+    'fibhip_spec_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
     'fibhip_trace_begin': ([_h], C.c_int),
     'fibhip_trace_end': ([_h, C.POINTER(TraceEvent), C.c_int], C.c_int),
     'fibhip_plan_tile': ([_h, _ip, _ip, _ip], C.c_int),
@@ -588,7 +589,11 @@ class Stepper:
         """{'launches', 'ticks', 'mt_launches', 'mt_ticks'} since the handle was created"""
         out = (C.c_longlong * 4)()
         self._ck(self._L.fibhip_launch_stats(self._h, out))
-        return dict(zip(('launches', 'ticks', 'mt_launches', 'mt_ticks'), [int(x) for x in out]))
+        d = dict(zip(('launches', 'ticks', 'mt_launches', 'mt_ticks'), [int(x) for x in out]))
+        sp = (C.c_longlong * 2)()
+        self._ck(self._L.fibhip_spec_stats(self._h, sp))
+        d.update(ahead_stopped_in_time=int(sp[0]), ahead_recomputed=int(sp[1]))
+        return d
 
     def ticks_per_launch(self):
         """consecutive ticks one launch can cover (Courtemanche, fast policy, one device: 3; Fenton / Beeler-Reuter on a

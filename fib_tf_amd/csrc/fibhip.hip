@@ -464,6 +464,7 @@ struct fibhip_ctx {
     int mt_max;             // most ticks one launch advances (<= 1: never)
     int mt_cur;             // ticks the next launch waits for: 1 after any observation of the state, then see fibhip_step
     long long n_ticks, n_mt_launches, n_mt_ticks;   // fibhip_launch_stats
+    long long n_spec_kept, n_spec_redone;           // series launched ahead that the caller cut short: stopped in time / recomputed
     int mt_run, mt_run_prev;        // ticks launched since the last observation of the state / between the two before it
     // run-ahead: a caller that alternates series of n ticks with ONE read-back (run() with image() every n ticks) gets the
     // next n ticks launched BEFORE the read-back's copy is waited for; see fibhip_get_state_direct
@@ -472,6 +473,11 @@ struct fibhip_ctx {
     int mt_run_prev2;               // the series before mt_run_prev
     bool series_fresh;              // ticks have run since the last observation of the state
     bool ahead_ok;                  // FIBHIP_AHEAD != 0
+    unsigned spec_id;               // ... of the launch that ran ahead
+    unsigned *host_word;            // page-locked, read by the tiles over PCIe: {launch id << 16 | n}, see flush()
+    unsigned *host_word_dev;        // its device address
+    unsigned mt_seq;                // id of the last multi-tick launch (the host's word names the launch it is meant for)
+    bool spec_trust;                // the caller has not broken a predicted series since its last two equal ones
     hipEvent_t ev_spec;
     unsigned *snap_flags;           // page-locked: one word per tile, raised by the tiles of a launch that carries a read-back
     unsigned snap_seq;
@@ -894,6 +900,9 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->mt_run = h->mt_run_prev = h->mt_run_prev2 = 0;
     h->spec_n = h->spec_used = 0;
     h->series_fresh = false;
+    h->spec_trust = true;
+    h->mt_seq = h->spec_id = 0;
+    h->host_word = h->host_word_dev = nullptr;
     h->snap_flags = nullptr;
     h->snap_seq = 0;
     {
@@ -901,7 +910,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         h->ahead_ok = !(e && atoi(e) == 0);
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
-    h->n_ticks = h->n_mt_launches = h->n_mt_ticks = 0;
+    h->n_ticks = h->n_mt_launches = h->n_mt_ticks = h->n_spec_kept = h->n_spec_redone = 0;
     h->mt_inflight = false;
     h->dead = false;
     {
@@ -910,7 +919,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         h->ncu = prop.multiProcessorCount;
         // FIBHIP_MT=0 switches multi-tick launches off, FIBHIP_MT_MAX bounds the ticks of one launch
         const char *e = getenv("FIBHIP_MT"), *em = getenv("FIBHIP_MT_MAX");
-        h->mt_max = (e && atoi(e) == 0) ? 1 : (em && atoi(em) > 0 ? atoi(em) : MT_MAX_TICKS);
+        h->mt_max = (e && atoi(e) == 0) ? 1 : (em && atoi(em) > 0 ? imin(atoi(em), 4096) : MT_MAX_TICKS);
         if (interleaved || desc->ghost_top || desc->ghost_bottom || (long long)h->cells * ((nv + 3) / 4 * 4) * 8 >= (1LL << 31))
             h->mt_max = 1;
     }
@@ -957,6 +966,7 @@ extern "C" int fibhip_destroy(fibhip_t h)
     if (h->agg) hipFree(h->agg);
     if (h->xbuf) hipFree(h->xbuf);
     if (h->epochs) hipFree(h->epochs);
+    if (h->host_word) hipHostFree(h->host_word);
     for (auto &r : h->trace) {
         if (r.e0) hipEventDestroy(r.e0);
         if (r.e1) hipEventDestroy(r.e1);
@@ -1170,6 +1180,7 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
             }
             h->spec_n = L;
             h->spec_used = 0;
+            h->spec_id = h->mt_seq;
             h->series_fresh = false;
             if (!in_launch) {
                 HIPCHK(wait_event(h->ev_spec));
@@ -1444,15 +1455,21 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
             h->xbuf = nullptr;
             return fail(FIBHIP_ENOMEM, "hipMalloc of the tick-exchange buffer failed");
         }
-        const size_t words = (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 2 * MT_EPOCH_STRIDE;
+        const size_t words = (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 3 * MT_EPOCH_STRIDE;
         if (hipMalloc((void **)&h->epochs, words * sizeof(unsigned)) != hipSuccess) {
             h->epochs = nullptr;
             return fail(FIBHIP_ENOMEM, "hipMalloc of the epoch words failed");
         }
         h->epochs_stale = true;
+        if (hipHostMalloc((void **)&h->host_word, 64, hipHostMallocDefault) != hipSuccess) {
+            h->host_word = nullptr;
+            return fail(FIBHIP_ENOMEM, "hipHostMalloc of the host's word failed");
+        }
+        *h->host_word = 0u;
+        HIPCHK(hipHostGetDevicePointer((void **)&h->host_word_dev, h->host_word, 0));
     }
     if (h->epochs_stale) {                            // first use, or the tiling may have changed: all words equal again
-        HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 2 * MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
+        HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 3 * MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
         h->epoch_base = 0;
         h->epochs_stale = false;
     }
@@ -1465,6 +1482,9 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     c.mt.epoch = h->epochs;
     c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
     c.mt.epoch0 = h->epoch_base;
+    h->mt_seq = h->mt_seq % 65535u + 1u;              // 1 .. 65535
+    c.mt.launch_id = h->mt_seq;
+    c.mt.host_word = h->host_word_dev;
     c.mt.nticks = T;
     if (v->kern_mt) {                                 // a kernel of a run-time module (launch_module lays the arguments out)
         c.kern = v->kern_mt;
@@ -1839,24 +1859,47 @@ static int launch_pending(fibhip_t h, int n)
 static int flush(fibhip_t h)
 {
     if (h->spec_n > 0) {
-        // The caller did not go on as predicted.  What it has been handed of the run-ahead (spec_used ticks) is recomputed
-        // from the state it started from — still intact: the launch wrote the other slab only — and the launch itself is
-        // told to stop at its next tick boundary (the cancel word, written through the second stream while it runs).
+        // The caller did not go on as predicted.  The launch that ran ahead is told so through the host's word (page-locked
+        // host memory; wave 0 of every tile reads it at the start of every tick and looks at it at the tick's end):
+        //  * some of its ticks have been handed out: "stop after spec_used ticks" — a tile leaves through its write-back at
+        //    that boundary, and counts itself.  The interpreter hands ticks out faster than the device computes them, so the
+        //    boundary is normally still ahead of every tile and nothing is computed twice; if a tile was past it already (it
+        //    then leaves without writing) the count falls short and the ticks are recomputed from the state the launch
+        //    started from — still intact: the launch writes the other slab only;
+        //  * none has: the launch is simply cancelled.
         const int redo = h->spec_used;
+        bool kept = false;
         if (h->epochs) {
-            unsigned one = 1u;
-            memcpy(h->probe_host + 9, &one, sizeof one);
-            HIPCHK(hipMemcpyAsync(h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + MT_EPOCH_STRIDE, h->probe_host + 9, sizeof one,
-                                  hipMemcpyHostToDevice, h->s1));
-            // whatever the main stream does next comes after that write (the launch it is meant for is already running there):
-            // the words are cleared again before the next multi-tick launch, and the write must not land after the clearing
-            HIPCHK(hipEventRecord(h->ev_int, h->s1));
-            HIPCHK(hipStreamWaitEvent(h->s0, h->ev_int, 0));
+            // (the word names the launch: earlier launches of this handle may still be queued or running)
+            unsigned word = (h->spec_id << 16) | (redo > 0 ? (unsigned)redo : MT_CANCEL);
+            // (a plain store: the tiles read this word over PCIe.  A copy through the second stream does not reach a device
+            // whose compute units are all taken before the launch has ended: measured at 512x512, 238-387 us)
+            __atomic_store_n(h->host_word, word, __ATOMIC_RELEASE);
+            unsigned *base = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
             h->epochs_stale = true;
+            if (redo > 0) {
+                HIPCHK(hipMemcpyAsync(h->probe_host + 10, base + 2 * MT_EPOCH_STRIDE, sizeof(unsigned), hipMemcpyDeviceToHost, h->s0));
+                SYNC_S0(h);
+                unsigned stopped;
+                memcpy(&stopped, h->probe_host + 10, sizeof stopped);
+                const Variant *v = mt_variant(h);
+                const long tiles = v ? (long)((h->d.width + v->TX - 1) / v->TX) * ((h->d.height + v->TY - 1) / v->TY) : -1;
+                kept = (long)stopped == tiles;
+            }
         }
         h->spec_n = h->spec_used = 0;
-        h->mt_run -= redo;
-        h->pending += redo;
+        if (kept) {                                 // the state after `redo` ticks is where the launch wrote it
+            memcpy(h->cur, h->spec_nxt, sizeof h->cur);
+            h->n_mt_launches++;
+            h->n_mt_ticks += redo;
+            h->n_ticks += redo;
+            h->n_spec_kept++;
+        } else {
+            h->mt_run -= redo;
+            h->pending += redo;
+            if (redo > 0) h->n_spec_redone++;
+        }
+        if (!kept && redo > 0) h->spec_trust = false;   // ONE sample is not believed again until two equal series were seen
     }
     const int rc = launch_pending(h, h->pending);
     h->series_fresh = h->mt_run > 0;
@@ -1864,6 +1907,7 @@ static int flush(fibhip_t h)
         h->mt_run_prev2 = h->mt_run_prev;
         h->mt_run_prev = h->mt_run;
         h->mt_run = 0;
+        if (h->mt_run_prev == h->mt_run_prev2) h->spec_trust = true;
     }
     h->mt_cur = 1;
     return rc;
@@ -1901,6 +1945,23 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // every waiting tick, up to mt_max.  mt_cur is 1 after any call that observes the state, so the device starts at once;
     // then the rest of the series if the caller works in series of equal length (run() with an image() every n ticks, a
     // benchmark region: the ticks between the last two observations), else 2, 4, ... mt_max while the caller keeps stepping.
+    // A series is launched WHOLE at its first tick when the caller's last series had that length (a benchmark region, run()
+    // with a probe or a sync every n ticks): one launch of n ticks instead of the first tick at once + the other n-1 when the
+    // last of them has arrived (at 512x512: the device idle while the interpreter makes its 19 other calls, and two launch
+    // prologues instead of one — 270 -> 247 us per 20-tick region).  It is the run-ahead of fibhip_get_state_direct started
+    // from here: the ticks are handed out below call by call, and a caller that does anything else first gets them recomputed
+    // / cancelled by flush() — after which ONE sample is not believed again until two equal series have been seen.
+    if (nticks > 0 && h->spec_n == 0 && h->mt_max > 1 && !h->tracing && h->ahead_ok && h->spec_trust && h->tuned && h->mt_run == 0 &&
+        h->pending == 0 && h->mt_run_prev >= 2 && h->mt_run_prev <= h->mt_max && nticks < h->mt_run_prev && h->pitch == h->d.width &&
+        h->phase_of_tick == 0 && h->has_consts) {
+        if (const Variant *v = mt_variant(h)) {
+            const int L = h->mt_run_prev;
+            if (int rc = mt_launch(h, v, L, false, h->spec_nxt)) return rc;
+            h->spec_n = L;
+            h->spec_used = 0;
+            h->spec_id = h->mt_seq;
+        }
+    }
     if (h->spec_n > 0 && nticks > 0) {                 // ticks that have been computed ahead already
         const int take = imin(nticks, h->spec_n - h->spec_used);
         h->spec_used += take;
@@ -2583,6 +2644,14 @@ extern "C" int fibhip_launch_stats(fibhip_t h, long long out[4])
     out[1] = h->n_ticks;
     out[2] = h->n_mt_launches;
     out[3] = h->n_mt_ticks;
+    return 0;
+}
+
+extern "C" int fibhip_spec_stats(fibhip_t h, long long out[2])
+{
+    if (!h || !out) return fail(FIBHIP_EINVAL, "spec_stats: null argument");
+    out[0] = h->n_spec_kept;
+    out[1] = h->n_spec_redone;
     return 0;
 }
 

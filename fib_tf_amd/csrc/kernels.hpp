@@ -434,8 +434,13 @@ __device__ unsigned long long fib_bstamps[4096 * 16];
 struct MtArgs {
     float *xb;            // exchange buffer
     unsigned *epoch;      // one word per tile, MT_EPOCH_STRIDE words apart
-    unsigned *err;        // [0]: a tile gave up waiting; [MT_EPOCH_STRIDE]: the host does not want this launch any more
+    unsigned *err;        // [0]: a tile gave up waiting; [MT_EPOCH_STRIDE]: the host's word as tile 0 passed it on; [2 * MT_EPOCH_STRIDE]:
+                          // tiles that stopped where it said (counted)
     unsigned epoch0;      // value of every epoch word when the launch starts
+    unsigned launch_id;   // 1 .. 65535: the host's word names the launch it is meant for in its upper half
+    const unsigned *host_word;   // page-locked HOST memory (device address): {launch_id << 16 | n}, written by the host while
+                          // the launch runs — n = MT_CANCEL: not wanted any more, else: stop after n ticks.  (A copy through
+                          // a second stream does not land before the launch has ended: measured, 512x512, 238-387 us.)
     int nticks;           // ticks this launch advances
     // read-back inside the launch (fibhip.hip `run-ahead`): every tile also writes array `snap_var` of the state the launch
     // STARTS from into page-locked host memory during its first ticks and then raises its word in `snap_flag` (host memory
@@ -447,6 +452,7 @@ struct MtArgs {
 };
 constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
 constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
+constexpr unsigned MT_CANCEL = 0xFFFFu;               // the host's word, low half: this launch is not wanted any more
 constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
 
 typedef unsigned fib_v4u __attribute__((ext_vector_type(4)));
@@ -590,6 +596,12 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr bool WHOLE_LOOP = MT && NV * R <= 12;
     const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
+    // the host's word is read over PCIe by ONE thread of the grid at the START of a tick and looked at at the tick's end: the
+    // round trip hides behind the sub-steps, at the price of seeing the word a tick late (see the tick boundary below)
+    unsigned hw = 0u;
+    if constexpr (MT) {
+        if (tile == 0 && threadIdx.x == 0) hw = __hip_atomic_load(mt.host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll 1
     for (int tick = 0;; ++tick) {
     if constexpr (MT) {
@@ -754,23 +766,44 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             const int d = lane < 4 ? lane : lane + 1;               // 0..8 without the centre
             const int ny = by + d / 3 - 1, nx = bx + d % 3 - 1;
             const bool need = lane < 8 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < g.tiles_x;
-            // lane 8 watches the give-up word instead, lane 9 the host's cancel word (one line further: a launch that ran
-            // ahead of the caller and is not wanted any more, fibhip.hip `run-ahead`)
+            // lane 8 watches the give-up word instead, lane 9 the host's word {launch id, n} (one line further; a launch that
+            // ran ahead of the caller, fibhip.hip `run-ahead`): not this launch's id (or 0) = go on; n = MT_CANCEL: the results
+            // are not wanted at all; else the caller wants the state after n ticks of this launch — this boundary if n ticks are
+            // done now (leave through the write-back), not this tile's business yet if n is still ahead, too late if it is
+            // behind.  (The id: earlier launches of the handle may still be queued or running when the word is written.)
+            // The word gets here through tile 0, which reads the host's page-locked copy over PCIe — ONE read per tick for the
+            // whole grid, issued at the start of a tick and looked at at its end, so the round trip hides behind the sub-steps —
+            // and passes it on.  (Measured: a copy through a second stream does not land before the launch has ended, 238-387 us
+            // at 512x512; every tile reading host memory itself costs 28 us per tick.)
+            if (tile == 0) {
+                const unsigned hws = __builtin_amdgcn_readfirstlane(hw);
+                if ((hws >> 16) == mt.launch_id && lane == 0)
+                    __hip_atomic_store(mt.err + MT_EPOCH_STRIDE, hws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
                                                                 : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE);
+            const unsigned done = (unsigned)tick + 1u;
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + MT_WAIT_TICKS;
             for (;;) {
                 const unsigned e = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool gave_up = __builtin_amdgcn_ballot_w64(lane == 8 && e != 0u) != 0ull;
-                const bool cancelled = __builtin_amdgcn_ballot_w64(lane == 9 && e != 0u) != 0ull;
-                // (epochs are compared as differences: they may wrap)
-                const bool ready = __builtin_amdgcn_ballot_w64(need && (int)(e - want) < 0) == 0ull;
-                if (ready && !gave_up && !cancelled) break;
-                if (cancelled) {                                    // not an error: the results are simply not wanted
-                    if (lane == 0) mt_abort = 1;
+                // one ballot for everything that is not the ordinary case: a tile gave up (lane 8), or the host's word concerns
+                // this boundary (lane 9)
+                const unsigned n_host = e & 0xFFFFu;
+                const bool special = lane == 8 ? e != 0u
+                                               : (lane == 9 && (e >> 16) == mt.launch_id && (n_host == MT_CANCEL || n_host <= done));
+                const unsigned long long sp = __builtin_amdgcn_ballot_w64(special);
+                if (sp != 0ull) {
+                    const bool gave_up = (sp >> 8) & 1ull;
+                    const bool stop_here = !gave_up && (__builtin_amdgcn_readlane(e, 9) & 0xFFFFu) == done;
+                    if (lane == 0) {
+                        if (gave_up) __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mt_abort = stop_here ? 2 : 1;               // 2: leave through the write-back (no neighbour is waited for: it
+                    }                                               // may have left already); 1: the results are not wanted / void
                     break;
                 }
-                if (gave_up || __builtin_amdgcn_s_memrealtime() > t_end) {
+                // (epochs are compared as differences: they may wrap)
+                if (__builtin_amdgcn_ballot_w64(need && (int)(e - want) < 0) == 0ull) break;
+                if (__builtin_amdgcn_s_memrealtime() > t_end) {
                     if (lane == 0) {
                         __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         mt_abort = 1;
@@ -783,7 +816,11 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         FIB_BSTAMP(4);
         __syncthreads();
         FIB_BSTAMP(5);
-        if (mt_abort) return;                                       // whole workgroup: the results of this launch are void
+        if (mt_abort == 1) return;                                  // whole workgroup: the results of this launch are void
+        if (mt_abort == 2) {                                        // the caller wants exactly the ticks done so far: write them back
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(mt.err + 2 * MT_EPOCH_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         // ---- the rim of the compute box, from what the neighbours published ------------------------------
         // (every load of handed-over bytes is an sc1 load; a thread outside the box or the grid reads a clamped
         // address like the prologue does: its values are never used)
@@ -853,6 +890,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         }
         FIB_BSTAMP_WAIT();
         FIB_BSTAMP(9);
+        // the host's word for the NEXT boundary: issued behind the last wait of this one (the counter of outstanding loads is
+        // in order: in front of the rim loads it would hold their wait back by a PCIe round trip)
+        if (tile == 0 && threadIdx.x == 0) hw = __hip_atomic_load(mt.host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     }
 

@@ -124,7 +124,8 @@ int fibhip_get_state(fibhip_t h, int var, float *dst);
  * Run-ahead: when the caller's last two series of ticks were equally long and each ended in one read-back of one array
  * (that very driver), this call launches the NEXT series before it returns — the frame then travels inside that launch
  * (the device writes `dst` itself) — and fibhip_step hands those ticks out without launching; any other call on the
- * handle first restores exactly the state the caller has been told about (ticks recomputed, the rest cancelled).
+ * handle first restores exactly the state the caller has been told about (the launch is stopped at the tick the caller
+ * has reached; if a tile is past it already, those ticks are recomputed and the rest cancelled).
  * Invisible except in time; FIBHIP_AHEAD=0 switches it off.                                                          */
 int fibhip_get_state_direct(fibhip_t h, int var, float *dst);
 int fibhip_host_alloc(size_t nbytes, void **out);
@@ -139,7 +140,10 @@ int fibhip_set_consts(fibhip_t h, const float *tbl, int n);
  * until a launch is worth issuing — the last tick of a call (fibhip_step_slow fuses with it), up to three ticks
  * (Courtemanche, fast policy) or up to 32 (Fenton / Beeler-Reuter on grids whose tiles are all resident at once: one
  * launch loops over them, see fibhip_ticks_per_launch) — and any call on the handle that observes or changes the state
- * launches what is held first: invisible to the caller except that work may be enqueued a few calls later.        */
+ * launches what is held first: invisible to the caller except that work may be enqueued a few calls later — or
+ * EARLIER: a caller whose last series of ticks (between two observations) had n ticks gets the next n launched at the
+ * first of them and handed out call by call; if it then stops after fewer, the running launch is told to stop at that
+ * tick (or, too late for that, those ticks are recomputed).  fibhip_spec_stats counts both outcomes.                 */
 int fibhip_step(fibhip_t h, int nticks);
 
 /* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and
@@ -282,6 +286,11 @@ int fibhip_ticks_per_launch(fibhip_t h);
 /* counters since fibhip_create: out[0] launches of any kernel, out[1] ticks advanced, out[2] multi-tick launches,
  * out[3] ticks those advanced (profiling scripts turn per-launch hardware counters into per-tick figures with them)  */
 int fibhip_launch_stats(fibhip_t h, long long out[4]);
+/* series of ticks that were launched ahead of the caller (fibhip_step: a whole series at its first tick when the last
+ * series had that length; fibhip_get_state_direct: the next series before the frame is waited for) and that the caller
+ * then cut short: out[0] launches that were stopped at the tick the caller had reached (nothing computed twice), out[1]
+ * launches whose handed-out ticks had to be recomputed.  No TensorFlow counterpart (ionic.py:202-204 is synchronous).   */
+int fibhip_spec_stats(fibhip_t h, long long out[2]);
 
 /* Timeline of the launches of a tick (ionic.py:231-241 traces one sess.run with TensorFlow's timeline and writes a
  * Chrome trace): between trace_begin and trace_end every kernel launch of the handle is bracketed by a pair of HIP

@@ -600,7 +600,8 @@ def test_fenton_multi_tick_launch_count(gpu_lib, monkeypatch):
     st.step(70)
     ms, launches = st.time_end()
     assert launches == 3, launches
-    # series of equal length (run() with an image() every 10 ticks): the first tick at once, the other nine together
+    # series of equal length (run() with an image() every 10 ticks): a series is ONE launch, issued at its first tick (the
+    # last series had that length) or by the read-back before it (the last two had)
     for _ in range(2):
         for _ in range(10):
             st.step(1)
@@ -609,7 +610,7 @@ def test_fenton_multi_tick_launch_count(gpu_lib, monkeypatch):
     for _ in range(10):
         st.step(1)
     ms, launches = st.time_end()
-    assert launches == 2, launches
+    assert launches == 1, launches
     stats = st.launch_stats()
     assert stats['ticks'] == 1 + 20 + 70 + 30 and stats['mt_ticks'] <= stats['ticks'] and stats['mt_launches'] >= 6, stats
     st.close()
@@ -800,6 +801,77 @@ def test_fenton_run_ahead_matches_one_launch_per_tick(gpu_lib, monkeypatch, poli
     assert steady == 1, 'a steady series should be one launch (the run-ahead), got %r' % steady
     assert len(a) == len(b)
     for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), 'observation %d differs' % i
+
+
+@pytest.mark.parametrize('model', ['fenton', 'br'])
+def test_series_launched_whole_and_cut_short(gpu_lib, monkeypatch, model):
+    """fibhip_step launches a whole series at its first tick when the caller's last series had that length (a benchmark
+    region, run() with a sync or probe every n ticks).  A caller that stops earlier than predicted gets the launch STOPPED at
+    the tick it has reached (the host's word, read by every tile at every tick boundary) — or, when a tile was past that tick
+    already, the ticks recomputed from the untouched state.  Either way every observation equals one launch per tick."""
+    import time
+    from fib_tf_amd import _lib
+    H, W = 130, 150
+    script = ([('steps', 12), ('sync',)] * 3 +                                  # the 2nd and 3rd series: one launch each
+              [('steps', 5), ('sync',), ('get',)] +                             # cut short: stopped at tick 5 (or recomputed)
+              [('steps', 5), ('sync',), ('steps', 5), ('probe',)] +
+              [('steps', 12), ('sync',), ('steps', 12), ('sync',)] +
+              [('steps', 4), ('sleep',), ('sync',), ('get',)] +                 # the launch of 12 has finished: too late to stop
+              [('steps', 9), ('pace',), ('steps', 9), ('sync',), ('steps', 20), ('getall',)])
+
+    def play(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        if model == 'fenton':
+            monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+            init, phi = _fenton_state(H, W, 41)
+            st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST)
+            st.set_phase(phi)
+            st.set_state(-1, init)
+            keep = None
+        else:
+            from fib_tf_amd.br import BeelerReuter
+            monkeypatch.setenv('FIBHIP_VARIANT', '5,54,21,-2')
+            keep = BeelerReuter(cfg(H, W, 0.809, 'fast', cheby=True, skip=False))
+            keep.add_hole_to_phase_field(40, 60, 15)
+            keep.define()
+            st = keep._stepper
+            st.pace(0, H // 2, 0, W // 2, 10.0, -100.0)
+        seen, per_series = [], []
+        for op in script:
+            l0 = st.launch_stats()['launches']
+            if op[0] == 'steps':
+                for _ in range(op[1]):
+                    st.step(1)
+                per_series.append(st.launch_stats()['launches'] - l0)
+            elif op[0] == 'sync':
+                st.sync()
+            elif op[0] == 'sleep':
+                time.sleep(0.05)
+            elif op[0] == 'get':
+                seen.append(st.get_state(0).copy())
+            elif op[0] == 'getall':
+                seen.append(st.get_state(-1))
+            elif op[0] == 'pace':
+                st.pace(10, 40, 20, 60, 1.0 if model == 'fenton' else 10.0, 0.0 if model == 'fenton' else -100.0)
+            elif op[0] == 'probe':
+                seen.append(np.float32(st.probe(0, 64, 75)))
+        stats = st.launch_stats()
+        st.close()
+        return seen, per_series, stats
+
+    a, series, sa = play(True)
+    b, _, sb = play(False)
+    assert sa['ticks'] == sb['ticks'] == sum(op[1] for op in script if op[0] == 'steps')
+    assert series[1] == 1 and series[2] == 1, 'a series of the predicted length should be one launch: %r' % (series,)
+    assert sa['ahead_stopped_in_time'] + sa['ahead_recomputed'] >= 2, sa
+    assert sa['ahead_recomputed'] >= 1, sa                     # (the series the caller slept on)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.isfinite(x).all()
         assert np.array_equal(x, y), 'observation %d differs' % i
 
 

@@ -165,6 +165,8 @@ def test_bench_spawns_its_ranks(gpu_lib):
     assert r.returncode == 0, r.stderr[-3000:]
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['ranks_in_communicator'] == 2
     assert line['value'] > 1000 and line['roofline']['us_per_launch'] > 0 and line['roofline']['whole_tick']['us_per_tick'] > 0
+    # the same grid on one device, measured by rank 0 after the ranks have left: what a scaling figure divides by
+    assert line['single_device_same_grid']['value'] > 1000, line['single_device_same_grid']
 
 
 def test_direct_rccl_exchange_self(gpu_lib, tmp_path):
