@@ -51,7 +51,6 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
 constexpr int AT_MT_TICKS = 8;           // autotune times a multi-tick candidate as one launch of this many ticks
-constexpr int MT_MAX_TILES = 1024;        // epoch words allocated per handle (only grids of <= ncu tiles use them)
 static const char *const MT_DEAD_MSG =
     "a multi-tick launch gave up: a tile waited 2 s for a neighbouring tile (were all workgroups resident? is another "
     "process holding the GPU?); the state of this handle is void — FIBHIP_MT=0 runs one launch per tick";
@@ -474,8 +473,8 @@ struct fibhip_ctx {
     bool series_fresh;              // ticks have run since the last observation of the state
     bool ahead_ok;                  // FIBHIP_AHEAD != 0
     unsigned spec_id;               // ... of the launch that ran ahead
-    unsigned *host_word;            // page-locked, read by the tiles over PCIe: {launch id << 16 | n}, see flush()
-    unsigned *host_word_dev;        // its device address
+    unsigned *host_word;            // page-locked (behind snap_flags), read by tile 0 over PCIe: {launch id << 16 | n}, see flush()
+    unsigned *snap_flags_dev;       // device address of snap_flags
     unsigned mt_seq;                // id of the last multi-tick launch (the host's word names the launch it is meant for)
     bool spec_trust;                // the caller has not broken a predicted series since its last two equal ones
     hipEvent_t ev_spec;
@@ -902,7 +901,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->series_fresh = false;
     h->spec_trust = true;
     h->mt_seq = h->spec_id = 0;
-    h->host_word = h->host_word_dev = nullptr;
+    h->host_word = h->snap_flags_dev = nullptr;
     h->snap_flags = nullptr;
     h->snap_seq = 0;
     {
@@ -966,7 +965,6 @@ extern "C" int fibhip_destroy(fibhip_t h)
     if (h->agg) hipFree(h->agg);
     if (h->xbuf) hipFree(h->xbuf);
     if (h->epochs) hipFree(h->epochs);
-    if (h->host_word) hipHostFree(h->host_word);
     for (auto &r : h->trace) {
         if (r.e0) hipEventDestroy(r.e0);
         if (r.e1) hipEventDestroy(r.e1);
@@ -1166,10 +1164,6 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
             void *dev_dst = nullptr;
             const bool in_launch = hipHostGetDevicePointer(&dev_dst, dst, 0) == hipSuccess && dev_dst != nullptr;
             if (!in_launch) (void)hipGetLastError();
-            if (in_launch && !h->snap_flags) {
-                HIPCHK(hipHostMalloc((void **)&h->snap_flags, (size_t)MT_MAX_TILES * MT_SNAP_STRIDE * sizeof(unsigned), hipHostMallocDefault));
-                memset(h->snap_flags, 0, (size_t)MT_MAX_TILES * MT_SNAP_STRIDE * sizeof(unsigned));
-            }
             if (in_launch) {
                 h->snap_seq++;
                 if (int rc = mt_launch(h, mv, L, false, h->spec_nxt, (float *)dev_dst, var)) return rc;
@@ -1461,12 +1455,14 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
             return fail(FIBHIP_ENOMEM, "hipMalloc of the epoch words failed");
         }
         h->epochs_stale = true;
-        if (hipHostMalloc((void **)&h->host_word, 64, hipHostMallocDefault) != hipSuccess) {
-            h->host_word = nullptr;
-            return fail(FIBHIP_ENOMEM, "hipHostMalloc of the host's word failed");
+        // page-locked: the tiles' words of a read-back inside a launch, and behind them the host's word (flush())
+        if (hipHostMalloc((void **)&h->snap_flags, ((size_t)MT_HOST_WORD_AT + 16) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+            h->snap_flags = nullptr;
+            return fail(FIBHIP_ENOMEM, "hipHostMalloc of the host-side words failed");
         }
-        *h->host_word = 0u;
-        HIPCHK(hipHostGetDevicePointer((void **)&h->host_word_dev, h->host_word, 0));
+        memset(h->snap_flags, 0, ((size_t)MT_HOST_WORD_AT + 16) * sizeof(unsigned));
+        HIPCHK(hipHostGetDevicePointer((void **)&h->snap_flags_dev, h->snap_flags, 0));
+        h->host_word = h->snap_flags + MT_HOST_WORD_AT;
     }
     if (h->epochs_stale) {                            // first use, or the tiling may have changed: all words equal again
         HIPCHK(hipMemsetAsync(h->epochs, 0, ((size_t)MT_MAX_TILES * MT_EPOCH_STRIDE + 3 * MT_EPOCH_STRIDE) * sizeof(unsigned), h->s0));
@@ -1483,9 +1479,7 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
     c.mt.epoch0 = h->epoch_base;
     h->mt_seq = h->mt_seq % 65535u + 1u;              // 1 .. 65535
-    c.mt.launch_id = h->mt_seq;
-    c.mt.host_word = h->host_word_dev;
-    c.mt.nticks = T;
+    c.mt.ticks_id = (unsigned)T | (h->mt_seq << 16);
     if (v->kern_mt) {                                 // a kernel of a run-time module (launch_module lays the arguments out)
         c.kern = v->kern_mt;
         c.kind = MK_STRIP_MT;
@@ -1494,7 +1488,7 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
         c.consts_bytes = h->mod ? h->mod->consts_bytes : 0;
     }
     c.mt.snap = snap;
-    c.mt.snap_flag = h->snap_flags;
+    c.mt.snap_flag = h->snap_flags_dev;
     c.mt.snap_seq = h->snap_seq;
     c.mt.snap_var = snap_var;
     {

@@ -437,26 +437,58 @@ struct MtArgs {
     unsigned *err;        // [0]: a tile gave up waiting; [MT_EPOCH_STRIDE]: the host's word as tile 0 passed it on; [2 * MT_EPOCH_STRIDE]:
                           // tiles that stopped where it said (counted)
     unsigned epoch0;      // value of every epoch word when the launch starts
-    unsigned launch_id;   // 1 .. 65535: the host's word names the launch it is meant for in its upper half
-    const unsigned *host_word;   // page-locked HOST memory (device address): {launch_id << 16 | n}, written by the host while
-                          // the launch runs — n = MT_CANCEL: not wanted any more, else: stop after n ticks.  (A copy through
-                          // a second stream does not land before the launch has ended: measured, 512x512, 238-387 us.)
-    int nticks;           // ticks this launch advances
+    unsigned ticks_id;    // low half: ticks this launch advances; high half: the launch's id, 1 .. 65535 (the host's word names
+                          // the launch it is meant for).  One word, and the host's word behind the tiles' words of `snap_flag`
+                          // instead of a pointer of its own: Beeler-Reuter's kernel spills scalar registers as it is, and three
+                          // more kernel arguments cost it 2.5 % (same-box A/B)
     // read-back inside the launch (fibhip.hip `run-ahead`): every tile also writes array `snap_var` of the state the launch
     // STARTS from into page-locked host memory during its first ticks and then raises its word in `snap_flag` (host memory
     // too, 64 bytes apart) to `snap_seq` — the host has the frame while the launch is still computing
     float *snap;
-    unsigned *snap_flag;
+    unsigned *snap_flag;  // page-locked HOST memory (device address): MT_MAX_TILES words MT_SNAP_STRIDE apart, then the host's
+                          // word {launch id << 16 | n}, written by the host while a launch runs — n = MT_CANCEL: not wanted any
+                          // more, else: stop after n ticks (always allocated, with or without a frame to deliver)
     unsigned snap_seq;
     int snap_var;
 };
+#ifndef FIB_POLL_SLEEP
+#define FIB_POLL_SLEEP 1
+#endif
 constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
+constexpr int MT_MAX_TILES = 1024;                    // epoch / snap words allocated per handle (only grids of <= ncu tiles use them)
+constexpr int MT_HOST_WORD_AT = MT_MAX_TILES * MT_SNAP_STRIDE;   // the host's word, in words from snap_flag
 constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
 constexpr unsigned MT_CANCEL = 0xFFFFu;               // the host's word, low half: this launch is not wanted any more
 constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
 
 typedef unsigned fib_v4u __attribute__((ext_vector_type(4)));
 typedef float fib_v4f __attribute__((ext_vector_type(4)));
+
+// M::pinned(k), or M::pinned_spare(k) where a model offers it and the kernel asks for it (one register less)
+template <class M, class = void>
+struct HasPinnedSpare {
+    static constexpr bool value = false;
+};
+template <class M>
+struct HasPinnedSpare<M, void_of<decltype(&M::pinned_spare)>> {
+    static constexpr bool value = true;
+};
+template <class A, class B>
+struct SameType {
+    static constexpr bool value = false;
+};
+template <class A>
+struct SameType<A, A> {
+    static constexpr bool value = true;
+};
+template <class M, bool SPARE, class C>
+static FIB_DEV decltype(auto) pinned_for(const C &k)
+{
+    if constexpr (SPARE && HasPinnedSpare<M>::value)
+        return M::pinned_spare(k);
+    else
+        return M::pinned(k);
+}
 
 // strip_kernel<M,P,MODE,K,TX,TY,R,PHASE> / strip_mt_kernel<...> share this body (MT = several ticks per launch)
 template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE, bool MT>
@@ -478,7 +510,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     if (tile >= g.ntiles) return;
     FIB_STAMP(0);
     if (MT && threadIdx.x == 0) mt_abort = 0;                       // (read after the first tick's barriers)
-    auto &&kk = M::pinned(k);
+    auto &&kk = pinned_for<M, (MT && SameType<P, Exact>::value)>(k);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int by = tile / g.tiles_x, bx = tile - by * g.tiles_x;
@@ -538,7 +570,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // have one boundary: stores here, word there.  Tried: the frame in three parts over three ticks, values re-read from the
     // slab — no faster, and the extra registers cost 2.7 %.)
     // (parked in LDS meanwhile: in registers they pushed the kernel to its 128-register budget and into scratch)
-    const int snap_at = (MT && mt.snap) ? (mt.nticks >= 3 ? 1 : 0) : -1;
+    const int snap_at = (MT && mt.snap) ? ((int)(mt.ticks_id & 0xFFFFu) >= 3 ? 1 : 0) : -1;
     if constexpr (MT) {
         if (mt.snap) {                                              // (wave-uniform)
 #pragma unroll
@@ -596,14 +628,22 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr bool WHOLE_LOOP = MT && NV * R <= 12;
     const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
-    // the host's word is read over PCIe by ONE thread of the grid at the START of a tick and looked at at the tick's end: the
-    // round trip hides behind the sub-steps, at the price of seeing the word a tick late (see the tick boundary below)
-    unsigned hw = 0u;
-    if constexpr (MT) {
-        if (tile == 0 && threadIdx.x == 0) hw = __hip_atomic_load(mt.host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 #pragma unroll 1
     for (int tick = 0;; ++tick) {
+    // the host's word is read over PCIe by ONE thread of the grid at the START of a tick and looked at at the tick's end: the
+    // round trip hides behind the sub-steps, at the price of seeing the word a tick late (see the tick boundary below).
+    // Issued HERE — nothing is outstanding at this point (the counter of outstanding loads is in order: in front of the rim
+    // loads of a boundary the PCIe round trip would hold their wait back) — and defined and used inside one pass of the tick
+    // loop: carried around the loop's back edge, the compiler waited for the load right where it was issued.
+    unsigned hw = 0u;
+    if constexpr (MT) {
+        if (tile == 0 && threadIdx.x == 0) {
+            typedef const __attribute__((address_space(1))) unsigned *gptr;     // (global, not flat: a flat load also counts
+            gptr p = (gptr)(mt.snap_flag + MT_HOST_WORD_AT);                                        // as an LDS operation, which every barrier waits for)
+            asm volatile("" : "+s"(p));                             // (a new address for the compiler in every tick: it had moved
+            hw = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the load in front of the tick loop)
+        }
+    }
     if constexpr (MT) {
         if (tick == snap_at) {
 #pragma unroll
@@ -723,7 +763,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         FIB_STAMP(3 + st);
     }
     }
-    if (!MT || tick + 1 >= mt.nticks) break;
+    if (!MT || tick + 1 >= (int)(mt.ticks_id & 0xFFFFu)) break;
 
     // ================= between two ticks of one launch =================
     if constexpr (MT) {
@@ -777,7 +817,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             // at 512x512; every tile reading host memory itself costs 28 us per tick.)
             if (tile == 0) {
                 const unsigned hws = __builtin_amdgcn_readfirstlane(hw);
-                if ((hws >> 16) == mt.launch_id && lane == 0)
+                if ((hws >> 16) == (mt.ticks_id >> 16) && lane == 0)
                     __hip_atomic_store(mt.err + MT_EPOCH_STRIDE, hws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
@@ -790,7 +830,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 // this boundary (lane 9)
                 const unsigned n_host = e & 0xFFFFu;
                 const bool special = lane == 8 ? e != 0u
-                                               : (lane == 9 && (e >> 16) == mt.launch_id && (n_host == MT_CANCEL || n_host <= done));
+                                               : (lane == 9 && (e >> 16) == (mt.ticks_id >> 16) && (n_host == MT_CANCEL || n_host <= done));
                 const unsigned long long sp = __builtin_amdgcn_ballot_w64(special);
                 if (sp != 0ull) {
                     const bool gave_up = (sp >> 8) & 1ull;
@@ -810,7 +850,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                     }
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(FIB_POLL_SLEEP);
             }
         }
         FIB_BSTAMP(4);
@@ -890,9 +930,6 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         }
         FIB_BSTAMP_WAIT();
         FIB_BSTAMP(9);
-        // the host's word for the NEXT boundary: issued behind the last wait of this one (the counter of outstanding loads is
-        // in order: in front of the rim loads it would hold their wait back by a PCIe round trip)
-        if (tile == 0 && threadIdx.x == 0) hw = __hip_atomic_load(mt.host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     }
 

@@ -403,6 +403,15 @@ struct Fenton {
         asm volatile("" : "+v"(c.dt), "+v"(c.ddt), "+v"(c.cvp), "+v"(c.cvn), "+v"(c.dvn), "+v"(c.cwp), "+v"(c.cwn), "+v"(c.dwn));
         return c;
     }
+    // the same with ONE scalar left where the compiler puts it (an SGPR: its one use per cell and sub-step issues a little
+    // slower): for the kernel that would otherwise exceed its register budget by exactly one — the multi-tick kernel under
+    // the rounding-faithful policy, which spilled a register to scratch memory (kernels.hpp strip_body)
+    static FIB_DEV Consts pinned_spare(const Consts &k)
+    {
+        Consts c = k;
+        asm volatile("" : "+v"(c.dt), "+v"(c.cvp), "+v"(c.cvn), "+v"(c.dvn), "+v"(c.cwp), "+v"(c.cwn), "+v"(c.dwn));
+        return c;
+    }
     // everything but the potential: s[1..3] advance, dU_out = the reaction term of the potential
     template <class P, class T>
     static FIB_DEV void pre(T (&s)[NVAR], T &dU_out, const Consts &k)

@@ -2,11 +2,15 @@
 // kernels.hpp:   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DKH='"path/kernels.hpp"' [-DNEW_ARGS] mt_ab.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include KH
 using namespace fib;
+#ifndef POLICY
+#define POLICY Fast
+#endif
 
 int main(int argc, char **argv)
 {
@@ -32,20 +36,20 @@ int main(int argc, char **argv)
     const int grid = ((g.ntiles + 7) / 8) * 8;
     unsigned epoch0 = 0;
     unsigned *hostw, *hostw_dev;
-    hipHostMalloc((void **)&hostw, 64, hipHostMallocDefault);
-    *hostw = 0;
+    hipHostMalloc((void **)&hostw, (MT_HOST_WORD_AT + 16) * sizeof(unsigned), hipHostMallocDefault);
+    memset(hostw, 0, (MT_HOST_WORD_AT + 16) * sizeof(unsigned));
     hipHostGetDevicePointer((void **)&hostw_dev, hostw, 0);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> us;
     for (int rep = 0; rep < reps + 5; ++rep) {
 #ifdef NEW_ARGS
-        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)rep + 1u, hostw_dev, T, nullptr, nullptr, 0, 0};
+        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, 0};
 #else
         MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, T, nullptr, nullptr, 0, 0};
 #endif
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((strip_mt_kernel<Fenton, Fast, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
+        hipLaunchKernelGGL((strip_mt_kernel<Fenton, POLICY, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;

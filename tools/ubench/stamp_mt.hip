@@ -5,6 +5,7 @@
 #define FIB_STAMPS 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include "../../fib_tf_amd/csrc/kernels.hpp"
@@ -37,11 +38,11 @@ int main(int argc, char **argv)
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     unsigned *hostw, *hostw_dev;                              // the host's word (never raised here)
-    hipHostMalloc((void **)&hostw, 64, hipHostMallocDefault);
-    *hostw = 0;
+    hipHostMalloc((void **)&hostw, (MT_HOST_WORD_AT + 16) * sizeof(unsigned), hipHostMallocDefault);
+    memset(hostw, 0, (MT_HOST_WORD_AT + 16) * sizeof(unsigned));
     hipHostGetDevicePointer((void **)&hostw_dev, hostw, 0);
     for (int rep = 0; rep < 5; ++rep) {
-        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)rep + 1u, hostw_dev, T, nullptr, nullptr, 0, 0};
+        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, 0};
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((strip_mt_kernel<Fenton, Fast, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
         hipEventRecord(e1, 0);
