@@ -875,6 +875,20 @@ def test_series_launched_whole_and_cut_short(gpu_lib, monkeypatch, model):
         assert np.array_equal(x, y), 'observation %d differs' % i
 
 
+def test_run_ahead_stress_in_lockstep(gpu_lib, monkeypatch):
+    """tools/dbg/stress_ahead.py for a few seconds: a multi-tick handle and a one-launch-per-tick handle driven in lockstep with
+    random series lengths, observations, host writes and pauses — the host's word arrives early, just in time and too late —
+    every observation bit-identical (a minute of it at 512x512: 70 000 series, 35 000 observations)"""
+    import subprocess
+    import sys
+    for k in ('FIBHIP_MT', 'FIBHIP_VARIANT', 'FIBHIP_AHEAD'):
+        monkeypatch.delenv(k, raising=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dbg', 'stress_ahead.py'), '6', '256'], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and 'stress ok' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_run_ahead_off_switch(gpu_lib, monkeypatch):
     from fib_tf_amd import _lib
     monkeypatch.setenv('FIBHIP_AHEAD', '0')
