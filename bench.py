@@ -366,8 +366,12 @@ def measure_single(args, exact, with_extras, snapshots=None, height=None, device
                         tile=(tw, th, tr), ticks_per_launch=max(1, nt // max(1, launches)) if multi else 1)
     if snapshots:
         m.image()                                     # set-up: the pinned staging buffer of the read-backs
-        ws = timed_regions(advance, st.sync, args.steps, args.repeats, snap=True)     # regions and median like `value`
+        def nlaunch2():
+            return st.launch_stats()['launches']
+        nlaunch2.log = []
+        ws = timed_regions(advance, st.sync, args.steps, args.repeats, snap=True, launches=nlaunch2)   # regions and median like `value`
         snaps = cells * args.steps * spt / statistics.median(ws) / 1e6
+        m._snap_regions = {'wall_ms_per_region': [round(w * 1e3, 4) for w in ws], 'launches_per_region': nlaunch2.log}
     return value, wall * 1000.0 / args.steps, roof, walls, snaps, m
 
 
@@ -435,6 +439,7 @@ def bench_single(args):
         'launches_per_region': getattr(m, '_launches_per_region', None),
         'roofline': roof,
         'value_with_snapshots': None if snaps is None else round(snaps, 1),
+        'snapshots_regions': getattr(m, '_snap_regions', None),
         'snapshots_note': 'median of %d regions of the same %d ticks with the reference driver\'s read-backs inside the timed '
                           'region: image() (the potential, into page-locked memory) every 10 ms of simulated time '
                           '(fenton.py:184-185)' % (args.repeats, args.steps),

@@ -470,6 +470,7 @@ struct fibhip_ctx {
     int spec_n, spec_used;          // ticks computed ahead of the caller / how many of them fibhip_step has handed out
     int spec_nxt[FIB_MAXVAR];       // where the state lives once all of them are handed out
     int mt_run_prev2;               // the series before mt_run_prev
+    int hist[8], nhist;             // lengths of the last series of ticks, oldest first (predict_series)
     bool series_fresh;              // ticks have run since the last observation of the state
     bool ahead_ok;                  // FIBHIP_AHEAD != 0
     unsigned spec_id;               // ... of the launch that ran ahead
@@ -897,6 +898,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->epochs_stale = true;
     h->mt_cur = 1;
     h->mt_run = h->mt_run_prev = h->mt_run_prev2 = 0;
+    h->nhist = 0;
     h->spec_n = h->spec_used = 0;
     h->series_fresh = false;
     h->spec_trust = true;
@@ -1071,6 +1073,7 @@ static Geo base_geo(const fibhip_ctx *h)
 // launches the tick fibhip_step may have left pending (defined with fibhip_step); every entry point that observes
 // or changes the state starts with it
 static int flush(fibhip_t h);
+static int predict_series(const fibhip_ctx *h, bool *repeat);
 struct Variant;
 static const Variant *mt_variant(const fibhip_ctx *h);
 static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_out, float *snap = nullptr, int snap_var = 0);
@@ -1149,7 +1152,7 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "get_state inside an open tick");
     // Run-ahead.  A caller that alternates series of n ticks with one read-back — IonicModel.run() with image() every n
     // ticks, fenton.py:184-185 — would leave the device idle for the whole read-back (34 us of a 125 us series at
-    // 512x512).  When the last two series were equally long, the next n ticks are launched HERE, before the frame is waited
+    // 512x512).  When the lengths of the last series repeat (predict_series), the next n ticks are launched HERE, before the frame is waited
     // for (the launch reads the slab the frame comes from and writes the other one).  fibhip_step then hands those ticks out
     // without launching anything; any other call first makes the state what the caller has been told it is (flush()).
     // The frame itself travels INSIDE that launch when the destination is page-locked memory the device can write
@@ -1157,10 +1160,12 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
     // while it starts computing and raises a word in host memory at its first tick boundary; this thread polls those words.
     // No copy engine, no blit kernel (which beside a grid that holds every compute unit would crawl: measured), no gap
     // between two series.  Any other destination: the copy goes first on the same stream and the launch right behind it.
-    if (var >= 0 && h->ahead_ok && !h->tracing && h->series_fresh && h->mt_run_prev >= 2 && h->mt_run_prev == h->mt_run_prev2 &&
-        h->mt_run_prev <= h->mt_max && h->pitch == h->d.width) {
+    bool repeats = false;
+    const int L_next = predict_series(h, &repeats);
+    if (var >= 0 && h->ahead_ok && !h->tracing && h->series_fresh && repeats && L_next >= 2 && L_next <= h->mt_max &&
+        h->pitch == h->d.width) {
         if (const Variant *mv = mt_variant(h)) {
-            const int L = h->mt_run_prev;
+            const int L = L_next;
             void *dev_dst = nullptr;
             const bool in_launch = hipHostGetDevicePointer(&dev_dst, dst, 0) == hipSuccess && dev_dst != nullptr;
             if (!in_launch) (void)hipGetLastError();
@@ -1416,6 +1421,30 @@ static int check_ready(fibhip_ctx *h)
 // must be ONE strip launch per tick whose tiles number at most the device's compute units — and no second such launch
 // of this process on the device at the same time (two half-resident grids would wait for each other until both
 // give up), which g_mt below guarantees.
+// How many ticks will the caller's next series (the ticks between two observations of the state) have?  From the lengths of
+// its last series: the same again if the last two were equal; if the lengths repeat with a period of 2, 3 or 4 — run() with an
+// image() every 10 ticks inside benchmark regions of 20 ticks that start 6 ticks before a read-back: 6, 10, 4, 6, 10, 4, ... —
+// the one that followed the last series' twin a period ago; else the last length (one sample).  `*repeat`: the prediction rests
+// on a repetition, not on one sample.  Wrong predictions cost little: too long, the launch is stopped at the tick the caller
+// reached (flush()); too short, the remaining ticks are launched the ordinary way.
+static int predict_series(const fibhip_ctx *h, bool *repeat)
+{
+    const int n = h->nhist;
+    if (repeat) *repeat = false;
+    if (n == 0) return 0;
+    const int *e = h->hist + n;                         // e[-1] = the last series
+    if (n >= 2 && e[-1] == e[-2]) {
+        if (repeat) *repeat = true;
+        return e[-1];
+    }
+    for (int p = 2; p <= 4; ++p)
+        if (n >= p + 1 && e[-1] == e[-1 - p]) {         // (ONE match is enough: a wrong guess is stopped or topped up)
+            if (repeat) *repeat = true;
+            return e[-p];
+        }
+    return e[-1];
+}
+
 static bool mt_eligible(const fibhip_ctx *h, const Variant *v)
 {
     if (h->mt_max <= 1 || !v || !v->fn_mt || v->K != h->spt || h->use_agg) return false;
@@ -1900,6 +1929,11 @@ static int flush(fibhip_t h)
     if (h->mt_run > 0) {                            // the caller is about to look: the next tick starts a new series
         h->mt_run_prev2 = h->mt_run_prev;
         h->mt_run_prev = h->mt_run;
+        if (h->nhist == 8) {
+            memmove(h->hist, h->hist + 1, 7 * sizeof(int));
+            h->nhist = 7;
+        }
+        h->hist[h->nhist++] = h->mt_run;
         h->mt_run = 0;
         if (h->mt_run_prev == h->mt_run_prev2) h->spec_trust = true;
     }
@@ -1945,11 +1979,12 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // prologues instead of one — 270 -> 247 us per 20-tick region).  It is the run-ahead of fibhip_get_state_direct started
     // from here: the ticks are handed out below call by call, and a caller that does anything else first gets them recomputed
     // / cancelled by flush() — after which ONE sample is not believed again until two equal series have been seen.
-    if (nticks > 0 && h->spec_n == 0 && h->mt_max > 1 && !h->tracing && h->ahead_ok && h->spec_trust && h->tuned && h->mt_run == 0 &&
-        h->pending == 0 && h->mt_run_prev >= 2 && h->mt_run_prev <= h->mt_max && nticks < h->mt_run_prev && h->pitch == h->d.width &&
-        h->phase_of_tick == 0 && h->has_consts) {
+    bool repeats = false;
+    const int L_next = (nticks > 0 && h->spec_n == 0 && h->mt_run == 0 && h->mt_max > 1) ? predict_series(h, &repeats) : 0;
+    if (L_next >= 2 && !h->tracing && h->ahead_ok && (repeats || h->spec_trust) && h->tuned && h->pending == 0 && L_next <= h->mt_max &&
+        nticks < L_next && h->pitch == h->d.width && h->phase_of_tick == 0 && h->has_consts) {
         if (const Variant *v = mt_variant(h)) {
-            const int L = h->mt_run_prev;
+            const int L = L_next;
             if (int rc = mt_launch(h, v, L, false, h->spec_nxt)) return rc;
             h->spec_n = L;
             h->spec_used = 0;
@@ -1982,7 +2017,7 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
                 if (int rc = tick_mt(h, v, T)) return rc;
                 const bool first = h->mt_run == 0;
                 h->mt_run += T;
-                const int rest = h->mt_run_prev - h->mt_run;
+                const int rest = predict_series(h, nullptr) - h->mt_run;
                 h->mt_cur = (first && rest >= 2) ? imin(rest, h->mt_max) : imin(2 * h->mt_cur, h->mt_max);
             }
             return 0;

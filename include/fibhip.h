@@ -121,8 +121,9 @@ int fibhip_get_state(fibhip_t h, int var, float *dst);
 /* The same read-back without the staging copy: `dst` should be page-locked memory from fibhip_host_alloc (the Python
  * binding keeps a small pool of such buffers behind the arrays `eval()` / `image()` return: the reference driver reads
  * the potential back 100 times per simulated second, fenton.py:184-185).
- * Run-ahead: when the caller's last two series of ticks were equally long and each ended in one read-back of one array
- * (that very driver), this call launches the NEXT series before it returns — the frame then travels inside that launch
+ * Run-ahead: when the lengths of the caller's last series of ticks repeat (the same again, or with a period of up to four:
+ * that very driver, also inside benchmark regions), this call launches the NEXT series before it returns — the frame
+ * then travels inside that launch
  * (the device writes `dst` itself) — and fibhip_step hands those ticks out without launching; any other call on the
  * handle first restores exactly the state the caller has been told about (the launch is stopped at the tick the caller
  * has reached; if a tile is past it already, those ticks are recomputed and the rest cancelled).

@@ -875,6 +875,45 @@ def test_series_launched_whole_and_cut_short(gpu_lib, monkeypatch, model):
         assert np.array_equal(x, y), 'observation %d differs' % i
 
 
+def test_periodic_series_are_predicted(gpu_lib, monkeypatch):
+    """series lengths that repeat with a period — 6 ticks + read-back, 10 + read-back, 4 + sync: run() with an image() every 10
+    ticks inside 20-tick benchmark regions — are launched whole from their second period on (one launch per series, the
+    read-backs' frames inside the launches of the series that follow them); every observation equals one launch per tick"""
+    from fib_tf_amd import _lib
+    H, W = 130, 150
+    init, phi = _fenton_state(H, W, 53)
+
+    def play(mt):
+        if mt:
+            monkeypatch.delenv('FIBHIP_MT', raising=False)
+        else:
+            monkeypatch.setenv('FIBHIP_MT', '0')
+        monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+        st = _lib.Stepper(_lib.FENTON4V, H, W, 0.1, 1.3, flags=_lib.FAST)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        seen, per_period = [], []
+        for period in range(5):
+            l0 = st.launch_stats()['launches']
+            for n, op in ((6, 'get'), (10, 'get'), (4, 'sync')):
+                for _ in range(n):
+                    st.step(1)
+                if op == 'get':
+                    seen.append(st.get_state(0).copy())
+                else:
+                    st.sync()
+            per_period.append(st.launch_stats()['launches'] - l0)
+        seen.append(st.get_state(-1))
+        st.close()
+        return seen, per_period
+
+    a, per = play(True)
+    b, _ = play(False)
+    assert per[-1] == 3 and per[-2] == 3, 'a predicted period of three series should be three launches: %r' % (per,)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), 'observation %d differs' % i
+
+
 def test_run_ahead_stress_in_lockstep(gpu_lib, monkeypatch):
     """tools/dbg/stress_ahead.py for a few seconds: a multi-tick handle and a one-launch-per-tick handle driven in lockstep with
     random series lengths, observations, host writes and pauses — the host's word arrives early, just in time and too late —
