@@ -956,6 +956,8 @@ extern "C" int fibhip_destroy(fibhip_t h)
     if (!h) return 0;
     fibhip_comm_free(h);
     hipSetDevice(h->d.device);
+    if (h->spec_n > 0 && h->host_word)                 // a launch that ran ahead of the caller: nobody wants its ticks any more
+        __atomic_store_n(h->host_word, (h->spec_id << 16) | MT_CANCEL, __ATOMIC_RELEASE);
     if (h->s0) hipStreamSynchronize(h->s0);
     if (h->s1) hipStreamSynchronize(h->s1);
     if (h->own_slab) {
