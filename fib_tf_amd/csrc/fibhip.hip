@@ -476,6 +476,7 @@ struct fibhip_ctx {
     unsigned spec_id;               // ... of the launch that ran ahead
     unsigned *host_word;            // page-locked (behind snap_flags), read by tile 0 over PCIe: {launch id << 16 | n}, see flush()
     unsigned *snap_flags_dev;       // device address of snap_flags
+    unsigned mt_ids;                // launch ids cycle through 1 .. mt_ids
     unsigned mt_seq;                // id of the last multi-tick launch (the host's word names the launch it is meant for)
     bool spec_trust;                // the caller has not broken a predicted series since its last two equal ones
     hipEvent_t ev_spec;
@@ -903,6 +904,10 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->series_fresh = false;
     h->spec_trust = true;
     h->mt_seq = h->spec_id = 0;
+    {
+        const char *e = getenv("FIBHIP_MT_IDS");
+        h->mt_ids = (e && atoi(e) >= 2 && atoi(e) <= 65535) ? (unsigned)atoi(e) : 65535u;
+    }
     h->host_word = h->snap_flags_dev = nullptr;
     h->snap_flags = nullptr;
     h->snap_seq = 0;
@@ -1509,7 +1514,9 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     c.mt.epoch = h->epochs;
     c.mt.err = h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE;
     c.mt.epoch0 = h->epoch_base;
-    h->mt_seq = h->mt_seq % 65535u + 1u;              // 1 .. 65535
+    h->mt_seq = h->mt_seq % h->mt_ids + 1u;           // 1 .. 65535 (FIBHIP_MT_IDS: a smaller cycle, for the tests)
+    // (the host's word keeps naming the last launch it was written for: that id is not given out again while it stands there)
+    if (h->host_word && (__atomic_load_n(h->host_word, __ATOMIC_RELAXED) >> 16) == h->mt_seq) h->mt_seq = h->mt_seq % h->mt_ids + 1u;
     c.mt.ticks_id = (unsigned)T | (h->mt_seq << 16);
     if (v->kern_mt) {                                 // a kernel of a run-time module (launch_module lays the arguments out)
         c.kern = v->kern_mt;
@@ -1885,7 +1892,7 @@ static int flush(fibhip_t h)
 {
     if (h->spec_n > 0) {
         // The caller did not go on as predicted.  The launch that ran ahead is told so through the host's word (page-locked
-        // host memory; wave 0 of every tile reads it at the start of every tick and looks at it at the tick's end):
+        // host memory; ONE thread of the grid reads it at the start of every tick and passes it on at the tick's end):
         //  * some of its ticks have been handed out: "stop after spec_used ticks" — a tile leaves through its write-back at
         //    that boundary, and counts itself.  The interpreter hands ticks out faster than the device computes them, so the
         //    boundary is normally still ahead of every tile and nothing is computed twice; if a tile was past it already (it

@@ -914,14 +914,20 @@ def test_periodic_series_are_predicted(gpu_lib, monkeypatch):
         assert np.array_equal(x, y), 'observation %d differs' % i
 
 
-def test_run_ahead_stress_in_lockstep(gpu_lib, monkeypatch):
-    """tools/dbg/stress_ahead.py for a few seconds: a multi-tick handle and a one-launch-per-tick handle driven in lockstep with
+@pytest.mark.parametrize('ids', [None, '16'])
+def test_run_ahead_stress_in_lockstep(gpu_lib, monkeypatch, ids):
+    """(ids = 16: launch ids cycle through 1 .. 16 instead of 1 .. 65535, so that the id the host's word still names comes
+    round again at once — it must not be given to another launch while the word stands there; a build without that rule fails
+    this case within 22 series)
+    tools/dbg/stress_ahead.py for a few seconds: a multi-tick handle and a one-launch-per-tick handle driven in lockstep with
     random series lengths, observations, host writes and pauses — the host's word arrives early, just in time and too late —
     every observation bit-identical (a minute of it at 512x512: 70 000 series, 35 000 observations)"""
     import subprocess
     import sys
-    for k in ('FIBHIP_MT', 'FIBHIP_VARIANT', 'FIBHIP_AHEAD'):
+    for k in ('FIBHIP_MT', 'FIBHIP_VARIANT', 'FIBHIP_AHEAD', 'FIBHIP_MT_IDS'):
         monkeypatch.delenv(k, raising=False)
+    if ids:
+        monkeypatch.setenv('FIBHIP_MT_IDS', ids)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dbg', 'stress_ahead.py'), '6', '256'], capture_output=True,
                        text=True, timeout=300)
