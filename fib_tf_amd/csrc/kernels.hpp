@@ -831,6 +831,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 const unsigned n_host = e & 0xFFFFu;
                 const bool special = lane == 8 ? e != 0u
                                                : (lane == 9 && (e >> 16) == (mt.ticks_id >> 16) && (n_host == MT_CANCEL || n_host <= done));
+                // (epochs are compared as differences: they may wrap)
+                const bool wait_more = need && (int)(e - want) < 0;
+                if (__builtin_amdgcn_ballot_w64(special || wait_more) == 0ull) break;      // the ordinary way out: ONE test
                 const unsigned long long sp = __builtin_amdgcn_ballot_w64(special);
                 if (sp != 0ull) {
                     const bool gave_up = (sp >> 8) & 1ull;
@@ -841,8 +844,6 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                     }                                               // may have left already); 1: the results are not wanted / void
                     break;
                 }
-                // (epochs are compared as differences: they may wrap)
-                if (__builtin_amdgcn_ballot_w64(need && (int)(e - want) < 0) == 0ull) break;
                 if (__builtin_amdgcn_s_memrealtime() > t_end) {
                     if (lane == 0) {
                         __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
