@@ -518,9 +518,15 @@ def spawn_ranks(args):
         return 2
     port = free_port()
     procs = []
+    # rank 0 writes its headline here before the side legs start: if a leg then takes a rank down (or all of them past the
+    # time limit), the headline measured before is relayed instead of being lost
+    import tempfile
+    fd, headline_file = tempfile.mkstemp(prefix='fibtf_headline_', suffix='.json')
+    os.close(fd)
+    os.unlink(headline_file)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', FIBTF_HEADLINE_FILE=headline_file)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     import threading
@@ -553,6 +559,18 @@ def spawn_ranks(args):
     reader.join(timeout=15)
     out = ''.join(chunks)
     lines = [l for l in out.splitlines() if l.startswith('{')]
+    if not lines and os.path.exists(headline_file):       # the ranks went down in a side leg: the headline stands
+        try:
+            early = json.load(open(headline_file))
+            early['side_legs_note'] = ('a rank failed or ran out of time in a side leg (exit status %d); this is the headline '
+                                       'rank 0 had written before the side legs started' % rc)
+            out += json.dumps(early) + '\n'
+            lines = [json.dumps(early)]
+            rc = 0
+        except (OSError, ValueError):
+            pass
+    if os.path.exists(headline_file):
+        os.unlink(headline_file)
     if rc == 0 and not lines:
         print('bench.py: rank 0 printed no result line', file=sys.stderr)
         rc = 1
@@ -562,66 +580,143 @@ def spawn_ranks(args):
     return rc
 
 
-def bench_ranks(args):
-    """this process is ONE rank of `world` (started by torch.distributed.run or by spawn_ranks)"""
-    import torch
-    import torch.distributed as dist
+def predicted_figure(size, world, scheme, transport):
+    """the figure tools/predict_scaling.py wrote for this (grid, ranks, halo scheme, transport) — kernels of one rank's
+    block measured on one MI355X, the exchange between two devices modelled — or None"""
+    try:
+        txt = open(os.path.join(ROOT, 'profiles', 'r03_predicted_scaling.txt')).read()
+    except OSError:
+        return None
+    import re
+    sect = None
+    for line in txt.splitlines():
+        if line.startswith('=='):
+            sect = 4096 if '4096' in line else (512 if '512x512' in line else None)
+        if sect != size:
+            continue
+        if world == 1:
+            mm = re.match(r'N=1:.*->\s*(\d+) Mcell-steps/s', line)
+            if mm:
+                return {'value': float(mm.group(1)), 'source': 'profiles/r03_predicted_scaling.txt'}
+            continue
+        mm = re.match(r'N=(\d+) (\w+) halo.*kernels\s+([\d.]+) us per tick.*\((\w+)\); predicted tick\s+([\d.]+) us ->\s*(\d+) Mcell-steps/s', line)
+        if mm and int(mm.group(1)) == world and mm.group(2) == scheme and mm.group(4) == transport:
+            return {'value': float(mm.group(6)), 'kernels_us_per_tick': float(mm.group(3)), 'tick_us': float(mm.group(5)),
+                    'transport_assumed': transport, 'source': 'profiles/r03_predicted_scaling.txt (kernels of one rank\'s block '
+                    'measured on one MI355X, the exchange between two devices modelled)'}
+    return None
+
+
+def block_kernels(m, st, H, local, spt, halo_ticks):
+    """rank 0's row block — owned + ghost rows, row offset, interleaved slab — as a stand-alone handle, its ticks timed with
+    HIP events on its stream: the block's kernels without any exchange.  (us per launch, launches, ticks, fused sub-steps)"""
     from fib_tf_amd import _lib
-    from fib_tf_amd.sharded import init_from_env
-    rank, world, local = init_from_env()
-    strong = args.scaling == 'strong'
-    H = args.size if strong else args.rows_per_gpu * world
-    m, (loc, amp, s2_ms) = make_model(args, height=H, device=local)
-    m.define()
-    m.add_pace_op('s2', loc, amp)
-    s2 = m.millisecond_to_step(s2_ms)
-    st = m._stepper
-    spt = m.dt_per_step
-    court = args.model == 'court'
-    advance = driver_loop(m, st, s2, court)
-
-    # (a one-rank group — only ever used to rehearse this path on one GPU — has a plain Stepper: no ghost zone)
-    halo_ticks, ghost, halo_n = getattr(st, 'halo_ticks', 1), getattr(st, 'g', 0), getattr(st, 'halo_n', 0)
-    advance(2 * halo_ticks)                             # set-up, not warm-up: two full exchange cycles create
-    st.sync()                                           # the RCCL channels and load the code objects
-    advance(args.setup // halo_ticks * halo_ticks)      # set-up: clocks in their steady state
-    advance(args.warmup)
-
-    def sync():
-        st.sync()
-        torch.cuda.synchronize()
-
-    comm0 = getattr(st, 'comm_s', 0.0)
-    walls = timed_regions(advance, sync, args.steps, args.repeats, barrier=dist.barrier)
-    wt = torch.tensor(walls, dtype=torch.float64, device='cuda')
-    dist.all_reduce(wt, op=dist.ReduceOp.MAX)                       # per region: the slowest rank
-    walls = [float(x) for x in wt.tolist()]
-    wall = statistics.median(walls)
-    comm = torch.tensor([getattr(st, 'comm_s', 0.0) - comm0], dtype=torch.float64, device='cuda')
-    dist.all_reduce(comm, op=dist.ReduceOp.MAX)
-    nranks = torch.tensor([1], dtype=torch.int32, device='cuda')
-    dist.all_reduce(nranks, op=dist.ReduceOp.SUM)                   # what the communicator itself counts
-    fused, per_tick = st.launch_plan()
-    backend = dist.get_backend()
-
-    # per-GPU kernel figure (rank 0): the same row block — owned + ghost rows, row offset, interleaved slab — as a
-    # stand-alone handle, ticks timed with HIP events on its stream: the block's kernels without any exchange
-    kern = None
-    if rank == 0 and hasattr(st, 'lh'):
-        espt = getattr(st, 'eng_spt', spt)                  # sub-steps per engine tick: 1 under --halo rows1
-        probe = _lib.Stepper(m.MODEL_ID, st.lh, m.width, m.dt, m.diff, flags=m._flags() | _lib.ROW_INTERLEAVED, device=local,
-                             steps_per_tick=espt, global_height=H, row_offset=st.lo, ghost_top=st.gt, ghost_bottom=st.gb,
-                             library=m._library)
+    espt = getattr(st, 'eng_spt', spt)                  # sub-steps per engine tick: 1 under --halo rows1
+    probe = _lib.Stepper(m.MODEL_ID, st.lh, m.width, m.dt, m.diff, flags=m._flags() | _lib.ROW_INTERLEAVED, device=local,
+                         steps_per_tick=espt, global_height=H, row_offset=st.lo, ghost_top=st.gt, ghost_bottom=st.gb,
+                         library=m._library)
+    try:
         m._configure_stepper(probe)
         if m.phase is not None:
             probe.set_phase(np.ascontiguousarray(m.phase[st.lo:st.lo + st.lh]))
         probe.set_state(-1, st.eng.get_state(-1))
         probe.step(2 * halo_ticks)
         probe.sync()
-        ms, launches = probe.time_steps(max(halo_ticks, 200 // halo_ticks * halo_ticks))
-        kern = (ms * 1000.0 / max(1, launches), launches, max(halo_ticks, 200 // halo_ticks * halo_ticks) * espt / float(spt),
-                probe.launch_plan()[0])
+        n = max(halo_ticks, 200 // halo_ticks * halo_ticks)
+        ms, launches = probe.time_steps(n)
+        return ms * 1000.0 / max(1, launches), launches, n * espt / float(spt), probe.launch_plan()[0]
+    finally:
         probe.close()
+
+
+def sharded_run(a, H, local, steps, repeats, setup, warmup):
+    """one grid in row blocks over the ranks of the default process group, driven and timed as the contract says: set-up
+    ticks, warm-up, `repeats` regions of exactly `steps` ticks between barrier + synchronisation, per region the max over
+    ranks.  Every rank calls it; returns what the result line is made of (the model and its stepper stay open)."""
+    import torch
+    import torch.distributed as dist
+    m, (loc, amp, s2_ms) = make_model(a, height=H, device=local)
+    m.define()
+    m.add_pace_op('s2', loc, amp)
+    s2 = m.millisecond_to_step(s2_ms)
+    st = m._stepper
+    advance = driver_loop(m, st, s2, a.model == 'court')
+    # (a one-rank group — only ever used to rehearse this path on one GPU — has a plain Stepper: no ghost zone)
+    halo_ticks = getattr(st, 'halo_ticks', 1)
+    advance(2 * halo_ticks)                             # set-up, not warm-up: two full exchange cycles create
+    st.sync()                                           # the RCCL channels and load the code objects
+    advance(setup // halo_ticks * halo_ticks)           # set-up: clocks in their steady state
+    advance(warmup)
+
+    def sync():
+        st.sync()
+        torch.cuda.synchronize()
+
+    comm0 = getattr(st, 'comm_s', 0.0)
+    walls = timed_regions(advance, sync, steps, repeats, barrier=dist.barrier)
+    wt = torch.tensor(walls, dtype=torch.float64, device='cuda')
+    dist.all_reduce(wt, op=dist.ReduceOp.MAX)                       # per region: the slowest rank
+    walls = [float(x) for x in wt.tolist()]
+    comm = torch.tensor([getattr(st, 'comm_s', 0.0) - comm0], dtype=torch.float64, device='cuda')
+    dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+    wall = statistics.median(walls)
+    return {'m': m, 'st': st, 'advance': advance, 'sync': sync, 'walls': walls, 'wall': wall, 'halo_wait': float(comm.item()),
+            'value': H * m.width * steps * m.dt_per_step / wall / 1e6, 'halo_ticks': halo_ticks,
+            'setup_ticks': 2 * halo_ticks + setup // halo_ticks * halo_ticks}
+
+
+def side_leg(a, H, local, rank, world, steps, repeats, setup, label):
+    """a bounded run of another configuration on the same ranks (every rank calls it): value, whole tick, rank 0's kernels"""
+    r = sharded_run(a, H, local, steps, repeats, setup, min(a.warmup, 8))
+    m, st = r['m'], r['st']
+    spt = m.dt_per_step
+    kern = None
+    if rank == 0 and hasattr(st, 'lh'):
+        kern = block_kernels(m, st, H, local, spt, r['halo_ticks'])
+    leg = None
+    if rank == 0:
+        scheme = getattr(st, 'halo_mode', 'ghost')
+        transport = 'library' if getattr(st, 'rccl_direct', False) else 'torch'
+        leg = {'config': label, 'value': round(r['value'], 1), 'unit': 'Mcell-steps/s', 'n_gpus': world,
+               'ms_per_step': round(r['wall'] * 1000.0 / steps, 6), 'steps': steps,
+               'timing': 'median of %d regions of %d ticks; per region the max over ranks' % (repeats, steps),
+               'wall_ms_per_region': [round(w * 1e3, 4) for w in r['walls']],
+               'whole_tick_us': round(r['wall'] * 1e6 / steps, 3), 'halo_scheme': scheme,
+               'halo_transport': getattr(st, 'halo_path', 'none'), 'halo_ticks': r['halo_ticks'],
+               'halo_wait_s_max_rank': round(r['halo_wait'], 4),
+               'predicted': predicted_figure(a.size, world, scheme, transport) if a.model == 'fenton' and not a.exact else None}
+        if kern:
+            us_l, launches, nt, kf = kern
+            leg['rank0_kernels_us_per_tick'] = round(us_l * launches / max(nt, 1e-9), 3)
+            leg['rank0_block'] = '%d owned + %d ghost rows x %d, K=%d' % (st.rows, st.lh - st.rows, m.width, kf)
+    st.sync()
+    st.close()
+    return leg
+
+
+def bench_ranks(args):
+    """this process is ONE rank of `world` (started by torch.distributed.run or by spawn_ranks)"""
+    import copy
+    import threading
+    import torch
+    import torch.distributed as dist
+    from fib_tf_amd.sharded import init_from_env
+    rank, world, local = init_from_env()
+    strong = args.scaling == 'strong'
+    H = args.size if strong else args.rows_per_gpu * world
+    r = sharded_run(args, H, local, args.steps, args.repeats, args.setup, args.warmup)
+    m, st, walls, wall = r['m'], r['st'], r['walls'], r['wall']
+    spt = m.dt_per_step
+    halo_ticks, ghost, halo_n = r['halo_ticks'], getattr(st, 'g', 0), getattr(st, 'halo_n', 0)
+    nranks = torch.tensor([1], dtype=torch.int32, device='cuda')
+    dist.all_reduce(nranks, op=dist.ReduceOp.SUM)                   # what the communicator itself counts
+    fused, per_tick = st.launch_plan()
+    backend = dist.get_backend()
+
+    # per-GPU kernel figure (rank 0): the same row block as a stand-alone handle, HIP-event timed
+    kern = None
+    if rank == 0 and hasattr(st, 'lh'):
+        kern = block_kernels(m, st, H, local, spt, halo_ticks)
 
     out = None
     if rank == 0:
@@ -649,6 +744,7 @@ def bench_ranks(args):
             roofline_extras(roof, kernel_key(args, args.exact, st.lh, m.width, kf, shard=True), us_l)
         else:
             roof.update({'achieved': roof['whole_tick']['achieved'], 'frac': roof['whole_tick']['frac']})
+        scheme = getattr(st, 'halo_mode', 'ghost')
         out = {
             'metric': 'million cell-steps/sec (grid_cells x timesteps / wall_s), %s %dx%d over %d GPUs' % (
                 {'fenton': '4v', 'br': 'BR', 'court': 'Courtemanche'}[args.model], H, m.width, world),
@@ -664,41 +760,156 @@ def bench_ranks(args):
                        'sub_steps_per_tick': spt, 'fused_sub_steps_per_launch': fused, 'launches_per_tick': per_tick,
                        'arithmetic': 'exact (one rounding per reference op)' if args.exact else 'fast_math (default policy)',
                        'parallelism': ('row-block x%d; one ghost row of the potential, exchanged after every sub-step (%d per tick), '
-                                       'edge rows first, interior on a second stream' % (world, spt)) if getattr(st, 'halo_mode', '') == 'rows1' else
+                                       'edge rows first, interior on a second stream' % (world, spt)) if scheme == 'rows1' else
                                       ('row-block x%d; ghost zone %d rows (= %d ticks): one point-to-point send/recv pair per '
                                        'neighbour every %d ticks, %d arrays in one contiguous message, interior '
                                        'overlapped on a second stream on tall blocks' % (world, ghost, halo_ticks, halo_ticks, halo_n)),
-                       'halo_scheme': getattr(st, 'halo_mode', 'ghost'),
+                       'halo_scheme': scheme,
                        'halo_transport': getattr(st, 'halo_path', 'none'), 'backend': backend,
                        'ranks_in_communicator': int(nranks.item()),
-                       'halo_wait_s_max_rank': round(float(comm.item()), 4), 'setup_ticks': 2 * halo_ticks + args.setup // halo_ticks * halo_ticks,
+                       'halo_wait_s_max_rank': round(r['halo_wait'], 4), 'setup_ticks': r['setup_ticks'],
                        'timing': 'median of %d regions of %d ticks; per region the max over ranks' % (args.repeats, args.steps)},
             'repeats': args.repeats, 'wall_ms_per_region': [round(w * 1e3, 4) for w in walls],
             'roofline': roof,
+            'predicted': predicted_figure(args.size, world, scheme, 'library' if getattr(st, 'rccl_direct', False) else 'torch')
+                         if args.model == 'fenton' and strong and not args.exact else None,
         }
-    # orderly teardown: every rank drains its stream and releases the library's communicator before anyone leaves
+
+    # ---- side legs: everything the first multi-GPU run has to answer beyond the headline --------------------------------------
+    # The headline is complete here.  It is written out (stderr, and the file the parent of self-spawned ranks watches) BEFORE
+    # any side leg starts, every leg is bounded, and a watchdog holds the whole lot to --side-budget seconds: when it runs out —
+    # a rank stuck in a collective cannot be called back — rank 0 prints the line as it stands and every rank leaves, so a leg
+    # that fails or stalls costs its own key (and the legs behind it), never the headline.
+    legs_done, legs_state = {}, {'current': None}
+    headline_file = os.environ.get('FIBTF_HEADLINE_FILE')
+
+    def emit_early():
+        if out is None:
+            return
+        early = dict(out, side_legs_note='written before the side legs started')
+        print('bench.py: headline before the side legs: %s' % json.dumps(early), file=sys.stderr, flush=True)
+        if headline_file:
+            with open(headline_file + '.tmp', 'w') as f:
+                f.write(json.dumps(early))
+            os.replace(headline_file + '.tmp', headline_file)
+
+    def give_up():
+        # (the watchdog's thread) nothing that needs the other ranks or the device from here on
+        if out is not None:
+            out.update(legs_done)
+            out['side_legs_timed_out'] = 'the side legs ran out of their %d s while in %r; the legs finished until then are in ' \
+                                         'this line, the headline above was complete before they started' % (args.side_budget, legs_state['current'])
+            print(json.dumps(out), flush=True)
+        sys.stderr.flush()
+        os._exit(0)
+
+    side = world > 1 and not args.no_side_legs
+    watchdog = None
+    if side:
+        emit_early()
+        watchdog = threading.Timer(args.side_budget, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def leg(name, fn):
+        legs_state['current'] = name
+        try:
+            res = fn()
+        except Exception as e:                          # (a failure on ONE rank leaves the others in a collective: the watchdog)
+            res = {'error': '%s: %s' % (type(e).__name__, e)}
+            print('bench.py: side leg %s failed on rank %d: %s' % (name, rank, res['error']), file=sys.stderr, flush=True)
+        if rank == 0 and res is not None:
+            legs_done[name] = res
+
+    parity = {}
+    if side:
+        # (a) the N-rank state against the one-device state of the same ticks, bitwise: from where the timed regions
+        # left it, two exchange cycles further; rank 0 repeats those ticks on ONE handle after the group is gone
+        def gather_parity():
+            T = 2 * halo_ticks
+            before = st.get_state(-1)
+            st.step(T)
+            after = st.get_state(-1)
+            if rank == 0:
+                parity.update(T=T, before=before, after=after)
+            return None
+        leg('sharded_equals_single', gather_parity)
+
     st.sync()
     dist.barrier()
-    if getattr(st, 'rccl_direct', False):
-        st.eng.st.comm_free()
+    direct = getattr(st, 'rccl_direct', False)
+    st.close()                                          # (releases the library's communicator, if any, first)
+    dist.barrier()
+
+    if side:
+        base = copy.copy(args)
+        base.scaling = 'strong'
+        # (b) north_star's own series: the 512x512 grid over the same N ranks
+        if not (args.size == 512 and strong and getattr(args, 'halo', None) in (None, 'ghost')) and 512 // world >= 10:
+            a = copy.copy(base)
+            a.size, a.halo, a.halo_ticks = 512, None, 0
+            leg('north_star_512', lambda: side_leg(a, 512, local, rank, world, 200, 3, 40,
+                                                   "north_star: Fenton 4v 512x512 over %d GPUs (strong scaling of BASELINE configs[1])" % world))
+        # (c) north_star's literal halo scheme on the headline's grid: one ghost row of the potential per sub-step
+        if getattr(args, 'halo', None) != 'rows1' and not args.skip:
+            a = copy.copy(base)
+            a.size, a.halo, a.halo_ticks = args.size, 'rows1', 0
+            leg('rows1_leg', lambda: side_leg(a, H, local, rank, world, 20, 3, 4,
+                                              "%s %dx%d over %d GPUs, halo scheme 'rows1' (one ghost row of the potential, exchanged after "
+                                              "every sub-step, interior on a second stream)" % (args.model, H, args.size, world)))
+        legs_state['current'] = 'teardown'
+
+    # orderly teardown: every rank has drained its stream and released the library's communicator before anyone leaves
     dist.barrier()
     dist.destroy_process_group()
-    if out is not None and not args.no_single_leg:
-        # rank 0, after the group is gone (the other ranks have left): the SAME grid on this one device, timed like the N = 1
-        # line times its workload — the denominator a scaling figure of this series needs (the N = 1 line of bench.py is
-        # BASELINE configs[1], another grid)
-        import copy
+    if watchdog is not None:
+        watchdog.cancel()
+    if out is not None:
+        out.update(legs_done)
+    if out is not None and (not args.no_single_leg or parity):
+        # rank 0, after the group is gone (the other ranks have left): the SAME grid on this one device — (1) the ticks of the
+        # parity leg repeated on one handle, compared bit for bit; (2) timed like the N = 1 line times its workload: the
+        # denominator a scaling figure of this series needs (the N = 1 line of bench.py is BASELINE configs[1], another grid)
         try:
-            st.close()
             a = copy.copy(args)
             a.steps, a.setup, a.warmup, a.repeats = max(10, min(args.steps, 100)), 30, 10, 3
-            v1, ms1, roof1, _, _, m1 = measure_single(a, args.exact, False, snapshots=False, height=H, device=local)
-            out['single_device_same_grid'] = {
-                'value': round(v1, 1), 'unit': 'Mcell-steps/s', 'ms_per_step': round(ms1, 6), 'steps': a.steps,
-                'plan': plan_text(m1._stepper), 'roofline_frac': roof1['frac'],
-                'note': 'the whole %dx%d grid as ONE handle on rank 0\'s device, median of 3 regions of %d ticks, measured in '
-                        'this run after the ranks had finished' % (H, m1.width, a.steps)}
-            m1._stepper.close()
+            if parity:
+                try:
+                    m1, _ = make_model(a, height=H, device=local)
+                    m1.define()
+                    s1 = m1._stepper
+                    s1.set_state(-1, parity['before'])
+                    s1.step(parity['T'])
+                    got = s1.get_state(-1)
+                    plan1 = plan_text(s1)
+                    s1.close()
+                    same = bool(np.array_equal(got.view(np.uint32), parity['after'].view(np.uint32)))
+                    out['sharded_equals_single'] = {
+                        'equal_bitwise': same, 'max_abs_diff': float(np.abs(got - parity['after']).max()), 'ticks': parity['T'],
+                        'arrays': int(got.shape[0]), 'note': 'state gathered from the %d ranks after the timed regions, %d more ticks '
+                        '(two exchange cycles) on the ranks, the same %d ticks from the same state on ONE handle on rank 0\'s device '
+                        '(its own launch plan: %s); every array compared bit for bit' % (world, parity['T'], parity['T'], plan1)}
+                except Exception as e:
+                    out['sharded_equals_single'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                parity.clear()
+            if not args.no_single_leg:
+                v1, ms1, roof1, _, _, m1 = measure_single(a, args.exact, False, snapshots=False, height=H, device=local)
+                out['single_device_same_grid'] = {
+                    'value': round(v1, 1), 'unit': 'Mcell-steps/s', 'ms_per_step': round(ms1, 6), 'steps': a.steps,
+                    'plan': plan_text(m1._stepper), 'roofline_frac': roof1['frac'],
+                    'note': 'the whole %dx%d grid as ONE handle on rank 0\'s device, median of 3 regions of %d ticks, measured in '
+                            'this run after the ranks had finished' % (H, m1.width, a.steps)}
+                m1._stepper.close()
+                pred = out.get('predicted') or {}
+                pred1 = predicted_figure(args.size, 1, 'ghost', 'torch') if pred else None
+                out['scaling_efficiency'] = {
+                    'speedup_vs_single_device_same_grid': round(out['value'] / v1, 4),
+                    'efficiency': round(out['value'] / v1 / world, 4), 'n_gpus': world,
+                    'predicted_speedup': round(pred['value'] / pred1['value'], 4) if pred and pred1 else None,
+                    'predicted_efficiency': round(pred['value'] / pred1['value'] / world, 4) if pred and pred1 else None,
+                    'note': 'value / single_device_same_grid.value (the same grid, the same run, rank 0\'s device) and that over the '
+                            'number of GPUs; the prediction is profiles/r03_predicted_scaling.txt\'s (made on one MI355X before any '
+                            'multi-GPU run)'}
         except Exception as e:                          # never lose the result line over the side leg
             out['single_device_same_grid'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if out is not None and not args.no_cpu:             # rank 0, after the group is gone: the other ranks have left
@@ -734,6 +945,10 @@ def main():
     ap.add_argument('--halo', default=None, choices=['ghost', 'rows1'],
                     help="N > 1: 'ghost' (default) = multi-tick ghost zone of all arrays; 'rows1' = north_star's literal scheme, one "
                          "ghost row of the potential exchanged after every sub-step, edge rows first, interior on a second stream")
+    ap.add_argument('--no-side-legs', action='store_true', help='N > 1: the headline only — no on-hardware parity check against one '
+                    'device, no 512x512 leg, no rows1 leg')
+    ap.add_argument('--side-budget', type=int, default=420, help='N > 1: seconds all side legs together may take before rank 0 prints '
+                    'the line as it stands and every rank leaves')
     ap.add_argument('--spawn-timeout', type=int, default=1500, help='N > 1 without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--force-dist', action='store_true', help='run the rank path even in a one-rank group (rehearsal)')
     args = ap.parse_args()

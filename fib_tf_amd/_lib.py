@@ -157,6 +157,9 @@ SYMBOLS = {
     'fibhip_ticks_per_launch': ([_h], C.c_int),
     'fibhip_launch_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
     'fibhip_spec_stats': ([_h, C.POINTER(C.c_longlong)], C.c_int),
+    'fibhip_fallbacks': ([_h, C.POINTER(C.c_longlong)], C.c_int),
+    'fibhip_set_mt_wait_ms': ([_h, C.c_int], C.c_int),
+    'fibhip_expect': ([_h, C.c_int], C.c_int),
     'fibhip_trace_begin': ([_h], C.c_int),
     'fibhip_trace_end': ([_h, C.POINTER(TraceEvent), C.c_int], C.c_int),
     'fibhip_plan_tile': ([_h, _ip, _ip, _ip], C.c_int),
@@ -424,6 +427,7 @@ class Stepper:
         d.module = getattr(L, 'module', None)          # a traced model's run-time module (ModuleLibrary), or NULL
         self._h = _h()
         self._L = L
+        self._warned = False
         self.nvar = self._ck(L.fibhip_nvar(model))
         self.height, self.width = height, width
         self.steps_per_tick = steps_per_tick or self._ck(L.fibhip_default_steps_per_tick(model))
@@ -459,9 +463,11 @@ class Stepper:
             out = _pinned_array(self._L, shape)
             if out is not None:
                 self._ck(self._L.fibhip_get_state_direct(self._h, var, _ptr(out)))
+                self._fallback_warning()
                 return out
         out = np.empty(shape, np.float32)
         self._ck(self._L.fibhip_get_state(self._h, var, _ptr(out)))
+        self._fallback_warning()
         return out
 
     def set_consts(self, tbl):
@@ -487,6 +493,31 @@ class Stepper:
 
     def sync(self):
         self._ck(self._L.fibhip_sync(self._h))
+        self._fallback_warning()
+
+    def expect(self, nticks):
+        """declares the caller's next series: `nticks` ticks without an observation in between (include/fibhip.h)"""
+        self._ck(self._L.fibhip_expect(self._h, int(nticks)))
+
+    def set_mt_wait_ms(self, ms):
+        self._ck(self._L.fibhip_set_mt_wait_ms(self._h, int(ms)))
+
+    def fallbacks(self):
+        """(multi-tick launches that gave up and were recovered, ticks recomputed one launch per tick)"""
+        out = (C.c_longlong * 2)()
+        self._ck(self._L.fibhip_fallbacks(self._h, out))
+        return int(out[0]), int(out[1])
+
+    def _fallback_warning(self):
+        if not self._warned:
+            n, ticks = self.fallbacks()
+            if n:
+                self._warned = True
+                import warnings
+                warnings.warn('fib_tf_amd: a launch advancing several ticks gave up waiting for a neighbouring tile (is another '
+                              'process holding the GPU, or a CU mask set?); the handle went back to the state that launch started '
+                              'from, recomputed %d tick(s) and runs one launch per tick from here on — same results, slower '
+                              '(FIBHIP_MT=0 selects that mode from the start)' % ticks, RuntimeWarning, stacklevel=3)
 
     def time_steps(self, nticks):
         ms, n = C.c_float(), C.c_int()
@@ -593,6 +624,8 @@ class Stepper:
         sp = (C.c_longlong * 2)()
         self._ck(self._L.fibhip_spec_stats(self._h, sp))
         d.update(ahead_stopped_in_time=int(sp[0]), ahead_recomputed=int(sp[1]))
+        fb = self.fallbacks()
+        d.update(gave_up_recovered=fb[0], ticks_recomputed_after_give_up=fb[1])
         return d
 
     def ticks_per_launch(self):

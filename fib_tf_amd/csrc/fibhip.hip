@@ -52,8 +52,9 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
 constexpr int AT_MT_TICKS = 8;           // autotune times a multi-tick candidate as one launch of this many ticks
 static const char *const MT_DEAD_MSG =
-    "a multi-tick launch gave up: a tile waited 2 s for a neighbouring tile (were all workgroups resident? is another "
-    "process holding the GPU?); the state of this handle is void — FIBHIP_MT=0 runs one launch per tick";
+    "a multi-tick launch gave up (a tile waited its full bound for a neighbouring tile: were all workgroups resident? is another "
+    "process holding the GPU?) and the state it started from could not be restored; the state of this handle is void — "
+    "FIBHIP_MT=0 runs one launch per tick";
 
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -483,7 +484,25 @@ struct fibhip_ctx {
     unsigned *snap_flags;           // page-locked: one word per tile, raised by the tiles of a launch that carries a read-back
     unsigned snap_seq;
     bool mt_inflight;       // a multi-tick launch has been issued since the give-up word was last read
-    bool dead;              // a multi-tick launch gave up waiting: the state is void
+    bool dead;              // a multi-tick launch gave up waiting and the state could not be restored: void
+    // A multi-tick launch that gives up must not cost the run (ionic.py:202-204 has no such failure).  Every such launch since
+    // the stream was last known good is remembered with the buffers it READ: a launch writes the other slab only and the
+    // launches queued behind a failed one find the give-up word at their first boundary and leave without writing, so the
+    // state the FIRST failed launch started from is intact when the host finds out (`recover`).
+    struct MtRec {
+        unsigned id;        // the launch's id (the give-up word names it)
+        int T;              // ticks it advances (a launch that ran ahead and was stopped in time: the ticks it did)
+        bool counted;       // the handle's state has moved past these ticks (false: a run-ahead not handed out yet)
+        int src[FIB_MAXVAR];
+    };
+    std::vector<MtRec> journal;
+    long long n_fallbacks, n_replayed;      // launches that gave up and were recovered / ticks recomputed one launch per tick
+    unsigned mt_wait_ms;    // a tile's bound on its wait for a neighbour (FIBHIP_MT_WAIT_MS, fibhip_set_mt_wait_ms); 0 = 2 s
+    long fake_giveup_at, fake_seen;         // test switch FIBHIP_MT_FAKE_GIVEUP=n: the n-th multi-tick launch finds the give-up word raised
+    bool recovering;
+    int expect;             // ticks the caller has DECLARED to come in one series (fibhip_expect) and that have not been asked for yet, or 0
+    bool expect_fresh;      // ... none of them has been asked for yet: the observation the caller makes first does not end the series
+    bool ptr_exposed;       // fibhip_state_ptr has handed out a raw pointer: the caller may write the state at any time
     int ncu;                // compute units of the device
     // fibhip_trace_begin / _end: the launches in between, each between two HIP events
     struct TraceRec {
@@ -912,8 +931,23 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     h->snap_flags = nullptr;
     h->snap_seq = 0;
     {
+        // Run-ahead starts the caller's NEXT ticks before it has asked for them.  A caller that owns the slabs
+        // (desc->ext_slab: it can write them between two calls without the library knowing) never gets it; a caller that has
+        // been handed a raw pointer (fibhip_state_ptr) loses it from then on — the same rule the aggregates follow.
         const char *e = getenv("FIBHIP_AHEAD");
-        h->ahead_ok = !(e && atoi(e) == 0);
+        h->ahead_ok = !(e && atoi(e) == 0) && h->own_slab;
+    }
+    h->n_fallbacks = h->n_replayed = 0;
+    h->recovering = false;
+    h->expect = 0;
+    h->expect_fresh = false;
+    h->ptr_exposed = false;
+    {
+        const char *e = getenv("FIBHIP_MT_WAIT_MS");
+        h->mt_wait_ms = (e && atol(e) > 0) ? (unsigned)(atol(e) > 0xFFFFFFl ? 0xFFFFFFl : atol(e)) : 0u;
+        const char *f = getenv("FIBHIP_MT_FAKE_GIVEUP");
+        h->fake_giveup_at = (f && atol(f) > 0) ? atol(f) : 0;
+        h->fake_seen = 0;
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
     h->n_ticks = h->n_mt_launches = h->n_mt_ticks = h->n_spec_kept = h->n_spec_redone = 0;
@@ -1031,6 +1065,43 @@ static hipError_t wait_event(hipEvent_t ev)
 }
 
 // wait for everything enqueued on the handle's stream; reports a multi-tick launch that gave up (strip_mt_kernel)
+static int tick_now(fibhip_t h);
+
+// A multi-tick launch gave up (the give-up word names it).  The stream is idle.  The launch wrote the other slab only, and
+// every multi-tick launch queued behind it left at its first boundary without writing: the state it STARTED from is where its
+// journal record says.  Go back there, switch multi-tick launches off for this handle, and recompute — one launch per tick,
+// bit-identical by construction — the ticks the handle's state had already moved past.
+static int recover(fibhip_ctx *h, unsigned id)
+{
+    size_t i = 0;
+    while (i < h->journal.size() && h->journal[i].id != id) ++i;
+    if (i == h->journal.size() || h->recovering) {
+        h->dead = true;
+        return fail(FIBHIP_EHIP, "%s", MT_DEAD_MSG);
+    }
+    int lost = 0;
+    for (size_t j = i; j < h->journal.size(); ++j)
+        if (h->journal[j].counted) lost += h->journal[j].T;
+    memcpy(h->cur, h->journal[i].src, sizeof h->cur);
+    h->journal.clear();
+    h->mt_max = 1;                                    // (mt_variant() is null from here on: no run-ahead, no series either)
+    h->mt_cur = 1;
+    h->epochs_stale = true;
+    HIPCHK(hipMemsetAsync(h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, 0, 3 * MT_EPOCH_STRIDE * sizeof(unsigned), h->s0));
+    h->n_fallbacks++;
+    h->n_replayed += lost;
+    h->recovering = true;
+    int rc = 0;
+    for (int t = 0; t < lost && rc == 0; ++t) rc = tick_now(h);
+    h->recovering = false;
+    if (rc) {
+        h->dead = true;
+        return rc;
+    }
+    HIPCHK(wait_stream(h->s0));
+    return 0;
+}
+
 static int sync_s0(fibhip_ctx *h)
 {
     const bool look = h->mt_inflight && h->epochs;
@@ -1042,10 +1113,8 @@ static int sync_s0(fibhip_ctx *h)
         h->mt_inflight = false;
         unsigned gave_up;
         memcpy(&gave_up, h->probe_host + 8, sizeof gave_up);
-        if (gave_up) {
-            h->dead = true;
-            return fail(FIBHIP_EHIP, "%s", MT_DEAD_MSG);
-        }
+        if (gave_up) return recover(h, gave_up);
+        h->journal.clear();                           // every launch so far has ended, and ended well
     }
     return 0;
 }
@@ -1167,10 +1236,15 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
     // while it starts computing and raises a word in host memory at its first tick boundary; this thread polls those words.
     // No copy engine, no blit kernel (which beside a grid that holds every compute unit would crawl: measured), no gap
     // between two series.  Any other destination: the copy goes first on the same stream and the launch right behind it.
+    if (int rc = journal_bound(h)) return rc;
     bool repeats = false;
-    const int L_next = predict_series(h, &repeats);
-    if (var >= 0 && h->ahead_ok && !h->tracing && h->series_fresh && repeats && L_next >= 2 && L_next <= h->mt_max &&
-        h->pitch == h->d.width) {
+    int L_next = predict_series(h, &repeats);
+    if (h->expect > 0 && h->expect_fresh) {           // the caller has said how many ticks it will ask for next (fibhip_expect)
+        L_next = imin(h->expect, h->mt_max);
+        repeats = true;
+    }
+    if (var >= 0 && h->ahead_ok && !h->tracing && (h->series_fresh || (h->expect > 0 && h->expect_fresh)) && repeats && L_next >= 2 &&
+        L_next <= h->mt_max && h->pitch == h->d.width && h->tuned) {
         if (const Variant *mv = mt_variant(h)) {
             const int L = L_next;
             void *dev_dst = nullptr;
@@ -1199,6 +1273,7 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
             const auto t0 = std::chrono::steady_clock::now();
             int next = 0;
             long spins = 0;
+            bool delivered = true;
             while (next < ntiles) {
                 if (fl[(size_t)next * MT_SNAP_STRIDE] == want) {
                     ++next;
@@ -1207,9 +1282,13 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
                 if ((++spins & 1023) == 0) {
                     // a launch that has ended without raising every word gave up (or was never resident): report it
                     if (hipStreamQuery(h->s0) == hipSuccess && fl[(size_t)next * MT_SNAP_STRIDE] != want) {
+                        // the launch gave up (or found the give-up word raised): nothing of it counts, the state it started
+                        // from stands (sync_s0 -> recover), and the frame comes the plain way, below
                         h->spec_n = 0;
                         SYNC_S0(h);
-                        return fail(FIBHIP_EHIP, "the launch that carried the read-back ended without delivering it");
+                        if (mt_variant(h)) return fail(FIBHIP_EHIP, "the launch that carried the read-back ended without delivering it");
+                        delivered = false;
+                        break;
                     }
                     (void)hipGetLastError();
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
@@ -1219,7 +1298,7 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            return 0;
+            if (delivered) return 0;
         }
     }
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
@@ -1528,7 +1607,23 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     c.mt.snap = snap;
     c.mt.snap_flag = h->snap_flags_dev;
     c.mt.snap_seq = h->snap_seq;
-    c.mt.snap_var = snap_var;
+    c.mt.snap_var = (snap_var & 0xFF) | (int)(h->mt_wait_ms << 8);
+    const bool trial = !commit && !nxt_out;           // (autotune: timed and checked on the spot, never part of the state)
+    if (!trial) {
+        fibhip_ctx::MtRec rec;
+        rec.id = h->mt_seq;
+        rec.T = T;
+        rec.counted = commit;
+        memcpy(rec.src, h->cur, sizeof rec.src);
+        h->journal.push_back(rec);
+        if (h->fake_giveup_at > 0 && ++h->fake_seen == h->fake_giveup_at) {
+            // test switch: this launch finds the give-up word raised in its name — what its tiles would have written had one
+            // of them waited out its bound — and leaves at its first boundary, like every launch behind it
+            unsigned *w = (unsigned *)(h->probe_host + 12);
+            *w = h->mt_seq;
+            HIPCHK(hipMemcpyAsync(c.mt.err, w, sizeof(unsigned), hipMemcpyHostToDevice, h->s0));
+        }
+    }
     {
         std::lock_guard<std::mutex> lock(g_mt.mu);
         fibhip_ctx *&owner = g_mt.owner[h->d.device];
@@ -1554,13 +1649,25 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
     return 0;
 }
 
-static int tick_now(fibhip_t h);
+// A caller that never synchronises must not grow the journal without bound: every 256 multi-tick launches the stream is
+// drained once (20 us in 100 ms of work) and the launches so far are confirmed — or the first that gave up is found.
+static int journal_bound(fibhip_ctx *h)
+{
+    if (h->journal.size() < 256 || h->spec_n > 0) return 0;
+    return sync_s0(h);
+}
 
 static int tick_mt(fibhip_t h, const Variant *v, int T)
 {
     if (T <= 1) return tick_now(h);
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
+    if (int rc = journal_bound(h)) return rc;
+    if (h->mt_max <= 1) {                             // (a launch among those just confirmed had given up: one launch per tick now)
+        for (int t = 0; t < T; ++t)
+            if (int rc = tick_now(h)) return rc;
+        return 0;
+    }
     return mt_launch(h, v, T, true, nullptr);
 }
 
@@ -1721,6 +1828,21 @@ static int autotune(fibhip_ctx *h)
             }
             HIPCHK(hipEventRecord(h->ev_t1, h->s0));
             HIPCHK(wait_event(h->ev_t1));
+            if (as_mt) {
+                // a candidate whose tiles could not all become resident (a CU mask, another process on the device) gave up
+                // waiting: it is dropped like one that could not be launched — the state is untouched, a trial writes the
+                // other slab only — and the words are cleared for the next candidate
+                unsigned gave_up = 0;
+                HIPCHK(hipMemcpy(&gave_up, h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, sizeof gave_up, hipMemcpyDeviceToHost));
+                if (gave_up) {
+                    failed[t] = true;
+                    h->epochs_stale = true;
+                    if (getenv("FIBHIP_PRINT_PLAN"))
+                        fprintf(stderr, "fibhip: %dx%d model %d: candidate K=%d tile %dx%d gave up waiting as a multi-tick launch: dropped\n",
+                                h->d.height, h->d.width, h->d.model, trial[0].K, trial[0].TX, trial[0].TY);
+                    continue;
+                }
+            }
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
             if (as_mt) ms /= (float)AT_MT_TICKS;
@@ -1920,6 +2042,11 @@ static int flush(fibhip_t h)
             }
         }
         h->spec_n = h->spec_used = 0;
+        for (auto &r : h->journal)                  // (the launch's journal record: what it did, if it did it)
+            if (r.id == h->spec_id) {
+                r.T = redo;
+                r.counted = kept;
+            }
         if (kept) {                                 // the state after `redo` ticks is where the launch wrote it
             memcpy(h->cur, h->spec_nxt, sizeof h->cur);
             h->n_mt_launches++;
@@ -1947,6 +2074,7 @@ static int flush(fibhip_t h)
         if (h->mt_run_prev == h->mt_run_prev2) h->spec_trust = true;
     }
     h->mt_cur = 1;
+    if (!h->expect_fresh) h->expect = 0;            // an observation inside a declared series ends the declaration
     return rc;
 }
 
@@ -1988,8 +2116,19 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
     // prologues instead of one — 270 -> 247 us per 20-tick region).  It is the run-ahead of fibhip_get_state_direct started
     // from here: the ticks are handed out below call by call, and a caller that does anything else first gets them recomputed
     // / cancelled by flush() — after which ONE sample is not believed again until two equal series have been seen.
+    // A caller that KNOWS its series says so (fibhip_expect: IonicModel.run() does, from its frame period and tick count) and
+    // nothing is guessed: the declared ticks are launched at the first of them, mt_max at a time.
+    if (int rc = journal_bound(h)) return rc;
     bool repeats = false;
-    const int L_next = (nticks > 0 && h->spec_n == 0 && h->mt_run == 0 && h->mt_max > 1) ? predict_series(h, &repeats) : 0;
+    int L_next = 0;
+    if (nticks > 0 && h->spec_n == 0 && h->mt_max > 1) {
+        if (h->expect > 0) {
+            L_next = imin(h->expect, h->mt_max);
+            repeats = true;
+        } else if (h->mt_run == 0) {
+            L_next = predict_series(h, &repeats);
+        }
+    }
     if (L_next >= 2 && !h->tracing && h->ahead_ok && (repeats || h->spec_trust) && h->tuned && h->pending == 0 && L_next <= h->mt_max &&
         nticks < L_next && h->pitch == h->d.width && h->phase_of_tick == 0 && h->has_consts) {
         if (const Variant *v = mt_variant(h)) {
@@ -2000,12 +2139,18 @@ extern "C" int fibhip_step(fibhip_t h, int nticks)
             h->spec_id = h->mt_seq;
         }
     }
+    if (h->expect > 0 && nticks > 0) {                 // (the declared series has begun / goes on)
+        h->expect = imax(0, h->expect - nticks);
+        h->expect_fresh = false;
+    }
     if (h->spec_n > 0 && nticks > 0) {                 // ticks that have been computed ahead already
         const int take = imin(nticks, h->spec_n - h->spec_used);
         h->spec_used += take;
         h->mt_run += take;
         nticks -= take;
         if (h->spec_used == h->spec_n) {             // all handed out: the state moves to where the launch put it
+            for (auto &r : h->journal)
+                if (r.id == h->spec_id) r.counted = true;
             memcpy(h->cur, h->spec_nxt, sizeof h->cur);
             h->n_mt_launches++;
             h->n_mt_ticks += h->spec_n;
@@ -2589,6 +2734,10 @@ extern "C" int fibhip_state_ptr(fibhip_t h, int var, void **dev_ptr)
 {
     if (!h || !dev_ptr || var < 0 || var >= h->nvar) return fail(FIBHIP_EINVAL, "state_ptr: bad argument");
     FLUSH(h);
+    // the caller may write the state through this pointer at any time, between any two calls: nothing may run ahead of it
+    // any more (a launch started before the caller asked for its ticks would read the state before such a write, or race it)
+    h->ptr_exposed = true;
+    h->ahead_ok = false;
     if (h->use_agg && !h->d.ghost_top && !h->d.ghost_bottom) {   // the caller may write through the pointer at any time: back to
                                                                  // the plain kernels (a shard's ghost rows: see create_impl)
         h->use_agg = false;
@@ -2690,6 +2839,29 @@ extern "C" int fibhip_spec_stats(fibhip_t h, long long out[2])
     if (!h || !out) return fail(FIBHIP_EINVAL, "spec_stats: null argument");
     out[0] = h->n_spec_kept;
     out[1] = h->n_spec_redone;
+    return 0;
+}
+
+extern "C" int fibhip_fallbacks(fibhip_t h, long long out[2])
+{
+    if (!h || !out) return fail(FIBHIP_EINVAL, "fallbacks: null argument");
+    out[0] = h->n_fallbacks;
+    out[1] = h->n_replayed;
+    return 0;
+}
+
+extern "C" int fibhip_set_mt_wait_ms(fibhip_t h, int ms)
+{
+    if (!h || ms < 0 || ms > 0xFFFFFF) return fail(FIBHIP_EINVAL, "set_mt_wait_ms: 0 (the default, 2000) .. 16777215");
+    h->mt_wait_ms = (unsigned)ms;
+    return 0;
+}
+
+extern "C" int fibhip_expect(fibhip_t h, int nticks)
+{
+    if (!h || nticks < 0) return fail(FIBHIP_EINVAL, "expect: bad argument");
+    h->expect = nticks;
+    h->expect_fresh = nticks > 0;
     return 0;
 }
 

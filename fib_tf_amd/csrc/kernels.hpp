@@ -449,10 +449,14 @@ struct MtArgs {
                           // word {launch id << 16 | n}, written by the host while a launch runs — n = MT_CANCEL: not wanted any
                           // more, else: stop after n ticks (always allocated, with or without a frame to deliver)
     unsigned snap_seq;
-    int snap_var;
+    int snap_var;         // low byte: which array the frame is; the other three: the bound on a tile's wait for its neighbours in
+                          // milliseconds (0 = MT_WAIT_TICKS; packed, not an argument of its own: see ticks_id)
 };
 #ifndef FIB_POLL_SLEEP
 #define FIB_POLL_SLEEP 1
+#endif
+#ifndef FIB_B_LASTWAVE
+#define FIB_B_LASTWAVE 0
 #endif
 constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
 constexpr int MT_MAX_TILES = 1024;                    // epoch / snap words allocated per handle (only grids of <= ncu tiles use them)
@@ -504,12 +508,16 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr unsigned WMASK = M::mask(MODE);
     __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
+    __shared__ unsigned mt_arrive;                                  // waves whose stores of the tick boundaries so far have been acknowledged
     __shared__ float snapl[MT ? NW * R * 64 : 1];                    // multi-tick launches: the frame's values, parked for one tick
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
     if (tile >= g.ntiles) return;
     FIB_STAMP(0);
-    if (MT && threadIdx.x == 0) mt_abort = 0;                       // (read after the first tick's barriers)
+    if (MT && threadIdx.x == 0) {
+        mt_abort = 0;                                               // (read after the first tick's barriers)
+        mt_arrive = 0u;                                             // (first added to after the first tick's barriers)
+    }
     auto &&kk = pinned_for<M, (MT && SameType<P, Exact>::value)>(k);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -577,7 +585,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             for (int r = 0; r < R; ++r) {
                 float x = s[r][0];
 #pragma unroll
-                for (int v = 1; v < NV; ++v) x = mt.snap_var == v ? s[r][v] : x;
+                for (int v = 1; v < NV; ++v) x = (mt.snap_var & 0xFF) == v ? s[r][v] : x;
                 snapl[(c0 + r) * 64 + lane] = x;                    // (read back by the same thread: no barrier needed)
             }
         }
@@ -625,7 +633,10 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // (and only where the registers are there and the bookkeeping is a visible share of the sub-step: four-row strips spilled
     // with the second loop — at 16 waves per workgroup the budget is 128 registers — and Beeler-Reuter's eight arrays with ~270
     // instructions per cell ran 1.5-3 % slower with it; both keep one loop)
-    constexpr bool WHOLE_LOOP = MT && NV * R <= 12;
+#ifndef FIB_WHOLE_NVR
+#define FIB_WHOLE_NVR 12
+#endif
+    constexpr bool WHOLE_LOOP = MT && NV * R <= FIB_WHOLE_NVR;
     const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
 #pragma unroll 1
@@ -787,11 +798,29 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             }
         }
         FIB_BSTAMP(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave, before the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave, before the barrier / before it is counted
         FIB_BSTAMP(2);
+        const unsigned want = mt.epoch0 + (unsigned)tick + 1u;
+#if FIB_B_LASTWAVE
+        // No workgroup barrier between the stores and the epoch word: every wave counts itself in LDS once its stores have
+        // been acknowledged, and the wave that comes LAST raises the word.  The strips that went stale early (the rim strips:
+        // nothing to store) pass at once — wave 0 among them, so its poll of the neighbours' words is already running when the
+        // tile's own word goes up — and nobody waits for the slowest strip twice.
+        {
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&mt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old + 1u == (unsigned)NW * ((unsigned)tick + 1u) && lane == 0) {
+                __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (every wave's write-through stores to the host frame have been acknowledged before it was counted)
+                if (tick == snap_at)
+                    __hip_atomic_store(mt.snap_flag + (size_t)tile * MT_SNAP_STRIDE, mt.snap_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        FIB_BSTAMP(3);
+#else
         __syncthreads();
         FIB_BSTAMP(3);
-        const unsigned want = mt.epoch0 + (unsigned)tick + 1u;
         if (threadIdx.x == 0) {
             __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // every wave's write-through stores to the host frame have been acknowledged (vmcnt(0) before the barrier above):
@@ -800,6 +829,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 __hip_atomic_store(mt.snap_flag + (size_t)tile * MT_SNAP_STRIDE, mt.snap_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+#endif
         // ---- wait for the eight neighbours (bounded) ---------------------------------------------------------
         if (wave == 0) {
             const int tiles_y = g.ntiles / g.tiles_x;
@@ -823,7 +853,8 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
                                                                 : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE);
             const unsigned done = (unsigned)tick + 1u;
-            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + MT_WAIT_TICKS;
+            const unsigned wait_ms = (unsigned)mt.snap_var >> 8;
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (wait_ms ? (unsigned long long)wait_ms * 100000ull : MT_WAIT_TICKS);
             for (;;) {
                 const unsigned e = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // one ballot for everything that is not the ordinary case: a tile gave up (lane 8), or the host's word concerns
@@ -839,14 +870,19 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                     const bool gave_up = (sp >> 8) & 1ull;
                     const bool stop_here = !gave_up && (__builtin_amdgcn_readlane(e, 9) & 0xFFFFu) == done;
                     if (lane == 0) {
-                        if (gave_up) __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (the give-up word stands already — it names the launch whose tile gave up first — and stays as it is)
                         mt_abort = stop_here ? 2 : 1;               // 2: leave through the write-back (no neighbour is waited for: it
                     }                                               // may have left already); 1: the results are not wanted / void
                     break;
                 }
                 if (__builtin_amdgcn_s_memrealtime() > t_end) {
                     if (lane == 0) {
-                        __hip_atomic_store(mt.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // the give-up word names the launch (its id is never 0): the host replays from the state THAT launch
+                        // started from (fibhip.hip, `recover`); launches queued behind it find the word and leave at their first
+                        // boundary without writing anything
+                        unsigned expected = 0u;
+                        __hip_atomic_compare_exchange_strong(mt.err, &expected, mt.ticks_id >> 16, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
                         mt_abort = 1;
                     }
                     break;

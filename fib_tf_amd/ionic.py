@@ -165,10 +165,16 @@ class IonicModel:
         self.samples = int(self.duration / (self.dt_per_step * self.dt))
         every = int(self.dt_per_plot / self.dt_per_step) if im else 0
         watch = {'v0': self.min_v, 'last_spike': 0}
+        # run() owns the cadence (ionic.py:199-206) and says so: with a screen the ticks up to the next frame are one series,
+        # without one the whole loop is (a loop body that reads something back earlier just ends the series there) — the
+        # library launches a declared series at its first tick instead of learning the pattern from the call history
+        if not every:
+            st.expect(self.samples)
         for i in range(self.samples):
             st.step(1)                           # == sess.run(self.ode_op(i)), ionic.py:203
             yield i
             if every and i % every == 0:         # a frame every dt_per_plot sub-steps, ionic.py:206
+                st.expect(min(every, self.samples - 1 - i))
                 self._paint(im, i, watch)
         if keep_state:                           # ionic.py:226-229
             self.state = {}

@@ -389,6 +389,9 @@ class ShardedStepper:
     def sync(self):
         self.eng.device_sync()
 
+    def expect(self, nticks):
+        """(row blocks advance tick by tick, exchange in between: nothing to declare)"""
+
     def time_steps(self, nticks):
         self.sync()
         self.dist.barrier(group=self.group)

@@ -127,7 +127,8 @@ int fibhip_get_state(fibhip_t h, int var, float *dst);
  * (the device writes `dst` itself) — and fibhip_step hands those ticks out without launching; any other call on the
  * handle first restores exactly the state the caller has been told about (the launch is stopped at the tick the caller
  * has reached; if a tile is past it already, those ticks are recomputed and the rest cancelled).
- * Invisible except in time; FIBHIP_AHEAD=0 switches it off.                                                          */
+ * Invisible except in time; FIBHIP_AHEAD=0 switches it off.  Never on caller-owned slabs (fibhip_desc.ext_slab) and never
+ * again once fibhip_state_ptr has handed out a raw pointer: such a caller may write the state between two calls.        */
 int fibhip_get_state_direct(fibhip_t h, int var, float *dst);
 int fibhip_host_alloc(size_t nbytes, void **out);
 int fibhip_host_free(void *p);
@@ -146,6 +147,14 @@ int fibhip_set_consts(fibhip_t h, const float *tbl, int n);
  * first of them and handed out call by call; if it then stops after fewer, the running launch is told to stop at that
  * tick (or, too late for that, those ticks are recomputed).  fibhip_spec_stats counts both outcomes.                 */
 int fibhip_step(fibhip_t h, int nticks);
+/* == the loop bounds of IonicModel.run() (ionic.py:199-206: `for i in range(samples)`, a frame every dt_per_plot ticks): the
+ * caller DECLARES that it will ask for the next `nticks` ticks as one series — no observation or change of the state in
+ * between; one observation may still come first (the frame that starts the series).  A declared series is launched at its
+ * first tick, up to fibhip_ticks_per_launch at a time, and handed out call by call; nothing is guessed from the call
+ * history (what fibhip_step does for callers that do not say).  A caller that breaks its word is served like one whose
+ * predicted series was wrong: the running launch is stopped at the tick reached.  0 withdraws the declaration.
+ * TensorFlow has no counterpart: sess.run is synchronous (ionic.py:202-204).                                          */
+int fibhip_expect(fibhip_t h, int nticks);
 
 /* == fire_op('slow') of Courtemanche (court.py:103,615-617): re-evaluates solve on the current state and
  * assigns the 17 slow variables.                                                                        */
@@ -282,7 +291,8 @@ int fibhip_plan_tile(fibhip_t h, int *tile_w, int *tile_h, int *rows_per_wave);
  * only the rim of their compute box from their neighbours between two ticks (no TensorFlow counterpart: ionic.py:202-204
  * issues one sess.run per tick).  A launch goes out as soon as the device would otherwise idle (see fibhip_step in
  * csrc/fibhip.hip); FIBHIP_MT=0 switches the mode off.  A tile of such a launch that waits 2 s for a neighbour gives up:
- * the next synchronising call returns FIBHIP_EHIP and the handle refuses further work.                           */
+ * the next synchronising call restores the state that launch started from and goes on with one launch per tick
+ * (fibhip_fallbacks).                                                                                             */
 int fibhip_ticks_per_launch(fibhip_t h);
 /* counters since fibhip_create: out[0] launches of any kernel, out[1] ticks advanced, out[2] multi-tick launches,
  * out[3] ticks those advanced (profiling scripts turn per-launch hardware counters into per-tick figures with them)  */
@@ -292,6 +302,14 @@ int fibhip_launch_stats(fibhip_t h, long long out[4]);
  * then cut short: out[0] launches that were stopped at the tick the caller had reached (nothing computed twice), out[1]
  * launches whose handed-out ticks had to be recomputed.  No TensorFlow counterpart (ionic.py:202-204 is synchronous).   */
 int fibhip_spec_stats(fibhip_t h, long long out[2]);
+/* Multi-tick launches that gave up waiting (a tile waited its full bound for a neighbour: not every workgroup was resident —
+ * a CU mask, another process holding the device) and were RECOVERED: the handle went back to the state the launch had
+ * started from (a launch writes the other slab only), switched multi-tick launches off for good and recomputed the lost
+ * ticks one launch per tick — bit-identical, only slower.  out[0] such launches, out[1] ticks recomputed.  Non-zero out[0]
+ * is worth a warning (fib_tf_amd prints one).  No TensorFlow counterpart (ionic.py:202-204 cannot fail this way).
+ * fibhip_set_mt_wait_ms: the bound, per handle (default 2000; FIBHIP_MT_WAIT_MS presets it).                          */
+int fibhip_fallbacks(fibhip_t h, long long out[2]);
+int fibhip_set_mt_wait_ms(fibhip_t h, int ms);
 
 /* Timeline of the launches of a tick (ionic.py:231-241 traces one sess.run with TensorFlow's timeline and writes a
  * Chrome trace): between trace_begin and trace_end every kernel launch of the handle is bracketed by a pair of HIP

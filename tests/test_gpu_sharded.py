@@ -167,6 +167,32 @@ def test_bench_spawns_its_ranks(gpu_lib):
     assert line['value'] > 1000 and line['roofline']['us_per_launch'] > 0 and line['roofline']['whole_tick']['us_per_tick'] > 0
     # the same grid on one device, measured by rank 0 after the ranks have left: what a scaling figure divides by
     assert line['single_device_same_grid']['value'] > 1000, line['single_device_same_grid']
+    # side legs (bench.py `bench_ranks`): the ranks' state against ONE handle advancing the same ticks, bit for bit, on the
+    # hardware the line was measured on; north_star's literal halo scheme on the same ranks; the scaling figure
+    eq = line['sharded_equals_single']
+    assert eq.get('equal_bitwise') is True and eq['max_abs_diff'] == 0.0 and eq['ticks'] >= 2, eq
+    assert line['rows1_leg']['value'] > 100 and line['rows1_leg']['halo_scheme'] == 'rows1', line['rows1_leg']
+    assert 'north_star_512' not in line                    # (the headline already is that grid)
+    se = line['scaling_efficiency']
+    assert abs(se['efficiency'] * 2 - se['speedup_vs_single_device_same_grid']) < 1e-3
+    assert line['predicted']['value'] > 0 and 'side_legs_timed_out' not in line
+
+
+def test_bench_side_legs_on_the_headline_grid(gpu_lib):
+    """the driver's plain `bench.py --gpus N` (BASELINE configs[3]: 4096x4096) rehearsed with 2 ranks sharing the one GPU:
+    the line carries the on-hardware parity statement, north_star's 512x512 series on the same ranks and the rows1 leg,
+    each with the figure predicted for it"""
+    r, line = _bench(['--gpus', '2', '--steps', '8', '--warmup', '4', '--setup', '8', '--no-cpu'],
+                     {'FIBTF_ONE_DEVICE': '1', 'FIBTF_DIST_BACKEND': 'gloo'}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line['n_gpus'] == 2 and '4096x4096' in line['metric'] and 'configs[3]' in line['config']['workload']
+    assert line['sharded_equals_single'].get('equal_bitwise') is True, line['sharded_equals_single']
+    ns = line['north_star_512']
+    assert ns['value'] > 1000 and ns['n_gpus'] == 2 and ns['predicted']['value'] > 0 and ns['rank0_kernels_us_per_tick'] > 0, ns
+    assert line['rows1_leg']['value'] > 100 and line['rows1_leg']['predicted']['value'] > 0, line['rows1_leg']
+    assert line['single_device_same_grid']['value'] > 1000 and line['scaling_efficiency']['predicted_efficiency'] > 0
+    # the headline was written out before the side legs started
+    assert 'headline before the side legs' in r.stderr
 
 
 def test_direct_rccl_exchange_self(gpu_lib, tmp_path):

@@ -170,6 +170,28 @@ def test_bench_cli_contract():
     assert bench.ALGO_BYTES['fenton'] + 4 == 36 and bench.ALGO_BYTES['br'] + 4 == 68
 
 
+def test_bench_multi_gpu_line_schema():
+    """the N > 1 line: what the first multi-GPU run must answer travels in the driver's plain invocation — the on-hardware
+    parity statement, north_star's 512x512 series, the rows1 leg, each next to its predicted figure (no GPU here: the keys are
+    pinned in the source, the prediction table is parsed for real)"""
+    import bench
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for key in ("'sharded_equals_single'", "'north_star_512'", "'rows1_leg'", "'scaling_efficiency'", "'single_device_same_grid'",
+                "'equal_bitwise'", "'max_abs_diff'", "'predicted'", "'side_legs_timed_out'", 'FIBTF_HEADLINE_FILE'):
+        assert key in src, key
+    assert src.index('emit_early()') < src.index("leg('sharded_equals_single'")      # the headline is out before any side leg
+    assert src.index("leg('sharded_equals_single'") < src.index('dist.destroy_process_group()')
+    for world in (2, 4, 8):
+        for size in (4096, 512):
+            for scheme in ('ghost', 'rows1'):
+                for transport in ('torch', 'library'):
+                    p = bench.predicted_figure(size, world, scheme, transport)
+                    assert p and p['value'] > 1000 and p['kernels_us_per_tick'] > 0 and p['tick_us'] >= p['kernels_us_per_tick'] - 1e-9
+    assert bench.predicted_figure(4096, 1, 'ghost', 'torch')['value'] > 3e5
+    assert bench.predicted_figure(4096, 8, 'ghost', 'torch')['value'] > bench.predicted_figure(4096, 4, 'ghost', 'torch')['value']
+    assert bench.predicted_figure(1000, 2, 'ghost', 'torch') is None
+
+
 def test_egm_masks_and_delay():
     """fib_tf_amd.egm host logic (egm.py:5-12 mask; two-electrode delay on synthetic upstrokes)"""
     from fib_tf_amd import egm
