@@ -199,6 +199,8 @@ def roofline_extras(roof, key, us_per_launch, own_time=False, tile=None, ticks_p
         us_per_launch = rec['us_per_launch_under_trace']
     t = rec.get('hbm_bytes_per_launch_corrected')
     roof['traffic'] = None if t is None else t * scale
+    if t is not None and us_per_launch > 0:           # what the launch really pulls from / pushes to HBM, against the peak
+        roof['hbm_traffic_frac'] = round(t * scale / (us_per_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     valu, trans = rec.get('SQ_INSTS_VALU'), rec.get('SQ_INSTS_VALU_TRANS_F32')
     if valu is not None:
         # wave-instructions per launch over all waves; a SIMD issues a wave64 VALU instruction in 2 cycles and a
@@ -239,7 +241,9 @@ def driver_loop(m, st, s2, court):
 
     def advance(n, snap=False):
         tick = state['tick']
-        for _ in range(n):
+        if not snap:
+            st.expect(n)                              # as run() does without a screen: the whole loop is one series
+        for k in range(n):
             st.step(1)
             if court and tick % 10 == 0:
                 st.step_slow()
@@ -248,6 +252,7 @@ def driver_loop(m, st, s2, court):
             if tick == s2:
                 m.fire_op('s2')
             if snap and tick % ds == 0:
+                st.expect(min(ds, n - 1 - k))         # as run(im) does before each frame: the ticks up to the next one
                 m.image()
             tick += 1
         state['tick'] = tick
@@ -352,6 +357,9 @@ def measure_single(args, exact, with_extras, snapshots=None, height=None, device
         roof['note'] += ('; one launch advances %d ticks: a tile keeps its cells in registers and re-reads the rim of its '
                          'compute box from its eight neighbours between two ticks (the state arrays are read at the first '
                          'and written at the last tick of a launch)' % (nt // max(1, launches)))
+        roof['frac_is'] = ('the ALGORITHMIC bytes of SURVEY 8d (what one pass per sub-step must move) per launch time over the HBM '
+                           'peak — an equivalent rate, not this launch\'s HBM traffic (`traffic`, `hbm_traffic_frac`), which is ~10x '
+                           'lower: the launch is bound by instruction issue (`issue`) and its tick boundaries, not by HBM')
     if court:
         roof['note'] += ('; Courtemanche: the timed mix is 9 fast ticks (%.0f B/cell) + 1 fused fast+slow tick '
                          '(%.0f B/cell) per 10, bytes and time both of the mix' % (COURT_FAST_BYTES + 4, COURT_SLOW_BYTES + 4))
@@ -500,6 +508,15 @@ def visible_devices():
             n = int(out.strip().splitlines()[-1])
         except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
             n = 0
+    # a lease that exposes only some of the node's GPUs (device cgroup) still shows every node in sysfs: what this process can
+    # OPEN is the render nodes it may read and write
+    try:
+        nodes = [f for f in os.listdir('/dev/dri') if f.startswith('renderD')]
+        usable = sum(1 for f in nodes if os.access(os.path.join('/dev/dri', f), os.R_OK | os.W_OK))
+        if nodes and n > usable:
+            n = usable
+    except OSError:
+        pass
     for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
         v = os.environ.get(var)
         if v is not None:

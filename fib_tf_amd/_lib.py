@@ -414,6 +414,10 @@ class Stepper:
                  global_height=0, row_offset=0, ghost_top=0, ghost_bottom=0, stream=None, ext_slabs=None,
                  library=None):
         L = library or lib()
+        # ANY other build of the library (a Beeler-Reuter table baked in, a traced model compiled in, an experiment's
+        # FIBHIP_BR_LIBRARY): the stock library's code object comes up first on this device — see `warm` — whoever the caller is
+        if library is not None and not isinstance(library, ModuleLibrary) and library is not lib():
+            warm(device)
         d = Desc()
         d.struct_size = C.sizeof(Desc)
         d.model, d.height, d.width = model, height, width
@@ -605,10 +609,12 @@ class Stepper:
 
     def trace_end(self):
         """[{'name', 'ts' (us from the first launch), 'dur' (us), 'K', 'tile', 'ticks'}] of the launches since trace_begin"""
-        ev = (TraceEvent * 64)()
-        n = self._ck(self._L.fibhip_trace_end(self._h, ev, 64))
+        cap = 1024
+        ev = (TraceEvent * cap)()
+        n = self._ck(self._L.fibhip_trace_end(self._h, ev, cap))
+        self.trace_truncated = n > cap                  # (more launches than the buffer holds: the first `cap` are returned)
         return [{'name': e.name.decode(), 'ts': e.start_us, 'dur': e.dur_us, 'K': e.K, 'tile': (e.tile_w, e.tile_h, e.rows_per_wave),
-                 'ticks': e.ticks} for e in ev[:n]]
+                 'ticks': e.ticks} for e in ev[:min(n, cap)]]
 
     def trace_tick(self):
         """one tick with every launch between two HIP events (the timeline of ionic.py:231-241)"""

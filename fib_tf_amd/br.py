@@ -150,15 +150,20 @@ class BeelerReuter(IonicModel):
                 _lib.warm(getattr(self, 'device', 0))       # the stock library's kernels first (include/fibhip.h fibhip_warm)
         return super()._new_stepper(steps_per_tick, shard)
 
-    def define(self, s1=True):
+    def define(self, s1=True, state=None):
         """initial conditions br.py:71-82 (S1: V[:,1] = 10 mV); one tick = 5 sub-steps, with
-        config['skip'] the slow gates advance 5·dt on the first of them only (br.py:98-107)"""
+        config['skip'] the slow gates advance 5·dt on the first of them only (br.py:98-107).
+        state: resume from a dict V/C/M/H/J/D/F/XI -> [H,W] array instead (`model.state` after
+        `run(keep_state=True)`; the contract of court.py:87-89)"""
         IonicModel.define(self)
-        shape = [self.height, self.width]
-        init = [np.full(shape, v, dtype=np.float32)
-                for v in (-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)]
-        if s1:
-            init[0][:, 1] = 10.0
+        if state is not None:
+            init = self._resume_arrays(state)
+        else:
+            shape = [self.height, self.width]
+            init = [np.full(shape, v, dtype=np.float32)
+                    for v in (-84.624, 1e-4, 0.01, 0.988, 0.975, 0.003, 0.994, 0.0001)]
+            if s1:
+                init[0][:, 1] = 10.0
         self._create(init)
         self._V = self._State['V']
 

@@ -1088,6 +1088,7 @@ static int recover(fibhip_ctx *h, unsigned id)
     h->mt_cur = 1;
     h->epochs_stale = true;
     HIPCHK(hipMemsetAsync(h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, 0, 3 * MT_EPOCH_STRIDE * sizeof(unsigned), h->s0));
+    __atomic_store_n(h->host_word + MT_GIVEUP_WORD, 0u, __ATOMIC_RELEASE);
     h->n_fallbacks++;
     h->n_replayed += lost;
     h->recovering = true;
@@ -1104,20 +1105,29 @@ static int recover(fibhip_ctx *h, unsigned id)
 
 static int sync_s0(fibhip_ctx *h)
 {
-    const bool look = h->mt_inflight && h->epochs;
-    if (look)
-        HIPCHK(hipMemcpyAsync(h->probe_host + 8, h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, sizeof(unsigned),
-                              hipMemcpyDeviceToHost, h->s0));
     HIPCHK(wait_stream(h->s0));
-    if (look) {
+    if (h->mt_inflight && h->epochs) {
+        // the tile that gave up first has written its launch's id into HOST memory (page-locked, behind the host's own word):
+        // nothing is copied from the device behind every launch (a 4-byte device-to-host copy at the end of every
+        // synchronising call cost a 20-tick benchmark region 5-7 us of its 250)
         h->mt_inflight = false;
-        unsigned gave_up;
-        memcpy(&gave_up, h->probe_host + 8, sizeof gave_up);
+        const unsigned gave_up = __atomic_load_n(h->host_word + MT_GIVEUP_WORD, __ATOMIC_ACQUIRE);
         if (gave_up) return recover(h, gave_up);
         h->journal.clear();                           // every launch so far has ended, and ended well
     }
     return 0;
 }
+// Nothing but another multi-tick launch is ever queued behind a multi-tick launch that has not been confirmed: a launch that
+// gave up leaves the state it started from intact only as long as whatever follows it writes nothing — multi-tick launches find
+// the give-up word and leave; a plain tick, a pace, a host write would not.  So those wait for the stream first.
+static int confirm(fibhip_ctx *h)
+{
+    return (h->mt_inflight && h->epochs) ? sync_s0(h) : 0;
+}
+#define CONFIRM(h)                                                                                 \
+    do {                                                                                           \
+        if (int rc_ = confirm(h)) return rc_;                                                      \
+    } while (0)
 #define SYNC_S0(h)                                                                                 \
     do {                                                                                           \
         if (int rc_ = sync_s0(h)) return rc_;                                                      \
@@ -1150,6 +1160,7 @@ static Geo base_geo(const fibhip_ctx *h)
 // or changes the state starts with it
 static int flush(fibhip_t h);
 static int predict_series(const fibhip_ctx *h, bool *repeat);
+static int journal_bound(fibhip_ctx *h);
 struct Variant;
 static const Variant *mt_variant(const fibhip_ctx *h);
 static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_out, float *snap = nullptr, int snap_var = 0);
@@ -1162,6 +1173,7 @@ extern "C" int fibhip_set_phase(fibhip_t h, const float *phi)
 {
     NEED(h);
     FLUSH(h);
+    CONFIRM(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_phase inside an open tick");
     if (!phi) {
         h->has_phase = false;
@@ -1182,6 +1194,7 @@ extern "C" int fibhip_set_state(fibhip_t h, int var, const float *src)
 {
     NEED(h);
     FLUSH(h);
+    CONFIRM(h);
     if (!src || var < -1 || var >= h->nvar) return fail(FIBHIP_EINVAL, "set_state: bad var %d", var);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "set_state inside an open tick");
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
@@ -1302,16 +1315,20 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
         }
     }
     const int v0 = var < 0 ? 0 : var, v1 = var < 0 ? h->nvar : var + 1;
-    for (int v = v0; v < v1; ++v) {
-        const float *src = h->slab[h->cur[v]] + (size_t)v * h->vstride;
-        float *d = dst + (size_t)(v - v0) * h->cells;
-        if (h->pitch == h->d.width)
-            HIPCHK(hipMemcpyAsync(d, src, h->cells * sizeof(float), hipMemcpyDeviceToHost, h->s0));
-        else
-            HIPCHK(hipMemcpy2DAsync(d, (size_t)h->d.width * sizeof(float), src, (size_t)h->pitch * sizeof(float),
-                                    (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
-    }
-    SYNC_S0(h);
+    for (int pass = 0; pass < 2; ++pass) {
+        const long long fb0 = h->n_fallbacks;
+        for (int v = v0; v < v1; ++v) {
+            const float *src = h->slab[h->cur[v]] + (size_t)v * h->vstride;
+            float *d = dst + (size_t)(v - v0) * h->cells;
+            if (h->pitch == h->d.width)
+                HIPCHK(hipMemcpyAsync(d, src, h->cells * sizeof(float), hipMemcpyDeviceToHost, h->s0));
+            else
+                HIPCHK(hipMemcpy2DAsync(d, (size_t)h->d.width * sizeof(float), src, (size_t)h->pitch * sizeof(float),
+                                        (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
+        }
+        SYNC_S0(h);
+        if (h->n_fallbacks == fb0) break;           // (else: a launch in front of the copy had given up — the state has been
+    }                                               // restored and recomputed meanwhile, and the copy is taken again)
     return 0;
 }
 
@@ -1326,10 +1343,14 @@ extern "C" int fibhip_get_state(fibhip_t h, int var, float *dst)
     // rate; the reference driver reads the potential back 100 times per simulated second (fenton.py:184-185)
     if (!h->stage) HIPCHK(hipHostMalloc((void **)&h->stage, h->cells * sizeof(float), hipHostMallocDefault));
     for (int v = v0; v < v1; ++v) {
-        HIPCHK(hipMemcpy2DAsync(h->stage, (size_t)h->d.width * sizeof(float),
-                                h->slab[h->cur[v]] + (size_t)v * h->vstride, (size_t)h->pitch * sizeof(float),
-                                (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
-        SYNC_S0(h);
+        for (int pass = 0; pass < 2; ++pass) {
+            const long long fb0 = h->n_fallbacks;
+            HIPCHK(hipMemcpy2DAsync(h->stage, (size_t)h->d.width * sizeof(float),
+                                    h->slab[h->cur[v]] + (size_t)v * h->vstride, (size_t)h->pitch * sizeof(float),
+                                    (size_t)h->d.width * sizeof(float), (size_t)h->d.height, hipMemcpyDeviceToHost, h->s0));
+            SYNC_S0(h);
+            if (h->n_fallbacks == fb0) break;       // (a launch in front of the copy had given up: recovered, copy again)
+        }
         memcpy(dst + (size_t)(v - v0) * h->cells, h->stage, h->cells * sizeof(float));
     }
     return 0;
@@ -1339,6 +1360,7 @@ extern "C" int fibhip_set_consts(fibhip_t h, const float *tbl, int n)
 {
     NEED(h);
     FLUSH(h);
+    CONFIRM(h);
     if (h->d.model != FIBHIP_BR || !(h->d.flags & FIBHIP_CHEBY))
         return fail(FIBHIP_EINVAL, "set_consts: only the Beeler-Reuter Chebyshev path takes a table");
     if (!tbl || n != 12 * 9) return fail(FIBHIP_EINVAL, "set_consts: expected 108 coefficients, got %d", n);
@@ -1622,6 +1644,7 @@ static int mt_launch(fibhip_t h, const Variant *v, int T, bool commit, int *nxt_
             unsigned *w = (unsigned *)(h->probe_host + 12);
             *w = h->mt_seq;
             HIPCHK(hipMemcpyAsync(c.mt.err, w, sizeof(unsigned), hipMemcpyHostToDevice, h->s0));
+            __atomic_store_n(h->host_word + MT_GIVEUP_WORD, h->mt_seq, __ATOMIC_RELEASE);      // (what that tile would also have written)
         }
     }
     {
@@ -1659,7 +1682,10 @@ static int journal_bound(fibhip_ctx *h)
 
 static int tick_mt(fibhip_t h, const Variant *v, int T)
 {
-    if (T <= 1) return tick_now(h);
+    if (T <= 1) {
+        CONFIRM(h);
+        return tick_now(h);
+    }
     if (h->phase_of_tick != 0) return fail(FIBHIP_EINVAL, "step: previous tick not committed");
     if (int rc = check_ready(h)) return rc;
     if (int rc = journal_bound(h)) return rc;
@@ -1832,11 +1858,11 @@ static int autotune(fibhip_ctx *h)
                 // a candidate whose tiles could not all become resident (a CU mask, another process on the device) gave up
                 // waiting: it is dropped like one that could not be launched — the state is untouched, a trial writes the
                 // other slab only — and the words are cleared for the next candidate
-                unsigned gave_up = 0;
-                HIPCHK(hipMemcpy(&gave_up, h->epochs + (size_t)MT_MAX_TILES * MT_EPOCH_STRIDE, sizeof gave_up, hipMemcpyDeviceToHost));
+                const unsigned gave_up = __atomic_load_n(h->host_word + MT_GIVEUP_WORD, __ATOMIC_ACQUIRE);
                 if (gave_up) {
                     failed[t] = true;
                     h->epochs_stale = true;
+                    __atomic_store_n(h->host_word + MT_GIVEUP_WORD, 0u, __ATOMIC_RELEASE);
                     if (getenv("FIBHIP_PRINT_PLAN"))
                         fprintf(stderr, "fibhip: %dx%d model %d: candidate K=%d tile %dx%d gave up waiting as a multi-tick launch: dropped\n",
                                 h->d.height, h->d.width, h->d.model, trial[0].K, trial[0].TX, trial[0].TY);
@@ -2082,6 +2108,7 @@ extern "C" int fibhip_step_edges(fibhip_t h)
 {
     NEED(h);
     FLUSH(h);
+    CONFIRM(h);
     return edges_impl(h);
 }
 
@@ -2297,6 +2324,7 @@ extern "C" int fibhip_pace(fibhip_t h, int r0, int r1, int c0, int c1, float v, 
 {
     NEED(h);
     FLUSH(h);
+    CONFIRM(h);
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "pace inside an open tick");
     const Geo g = base_geo(h);
     if (int rc = trace_open(h, h->s0, "pace_kernel", 1, 0, 0, 0, 1)) return rc;
@@ -2314,9 +2342,13 @@ extern "C" int fibhip_probe(fibhip_t h, int var, int row, int col, float *out)
     if (!out || var < 0 || var >= h->nvar || row < 0 || row >= h->d.height || col < 0 || col >= h->d.width)
         return fail(FIBHIP_EINVAL, "probe: out of range");
     if (h->phase_of_tick) return fail(FIBHIP_EINVAL, "probe inside an open tick");
-    HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->vstride + (size_t)row * h->pitch + col,
-                          sizeof(float), hipMemcpyDeviceToHost, h->s0));
-    SYNC_S0(h);
+    for (int pass = 0; pass < 2; ++pass) {
+        const long long fb0 = h->n_fallbacks;
+        HIPCHK(hipMemcpyAsync(h->probe_host, h->slab[h->cur[var]] + (size_t)var * h->vstride + (size_t)row * h->pitch + col,
+                              sizeof(float), hipMemcpyDeviceToHost, h->s0));
+        SYNC_S0(h);
+        if (h->n_fallbacks == fb0) break;           // (a launch in front of the copy had given up: recovered, copy again)
+    }
     *out = *h->probe_host;
     return 0;
 }
@@ -2811,7 +2843,10 @@ extern "C" int fibhip_trace_end(fibhip_t h, fibhip_trace_event *out, int max_eve
     SYNC_S0(h);
     int n = 0;
     for (const auto &r : h->trace) {
-        if (n >= max_events) break;
+        if (n >= max_events) {                        // (like snprintf: the return value says how many there were)
+            n = (int)h->trace.size();
+            break;
+        }
         float t0 = 0.f, dur = 0.f;
         HIPCHK(hipEventElapsedTime(&t0, h->trace[0].e0, r.e0));
         HIPCHK(hipEventElapsedTime(&dur, r.e0, r.e1));

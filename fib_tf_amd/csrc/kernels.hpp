@@ -461,6 +461,7 @@ struct MtArgs {
 constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
 constexpr int MT_MAX_TILES = 1024;                    // epoch / snap words allocated per handle (only grids of <= ncu tiles use them)
 constexpr int MT_HOST_WORD_AT = MT_MAX_TILES * MT_SNAP_STRIDE;   // the host's word, in words from snap_flag
+constexpr int MT_GIVEUP_WORD = 8;                     // ... and, this many words behind it, the id of the launch whose tile gave up first
 constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
 constexpr unsigned MT_CANCEL = 0xFFFFu;               // the host's word, low half: this launch is not wanted any more
 constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
@@ -508,7 +509,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr unsigned WMASK = M::mask(MODE);
     __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
-    __shared__ unsigned mt_arrive;                                  // waves whose stores of the tick boundaries so far have been acknowledged
+    __shared__ unsigned mt_arrive[FIB_B_LASTWAVE ? 1 : 0 + 1];      // (FIB_B_LASTWAVE, measured and not taken: waves whose stores have been acknowledged)
     __shared__ float snapl[MT ? NW * R * 64 : 1];                    // multi-tick launches: the frame's values, parked for one tick
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);
@@ -516,7 +517,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     FIB_STAMP(0);
     if (MT && threadIdx.x == 0) {
         mt_abort = 0;                                               // (read after the first tick's barriers)
-        mt_arrive = 0u;                                             // (first added to after the first tick's barriers)
+        if (FIB_B_LASTWAVE) mt_arrive[0] = 0u;                         // (first added to after the first tick's barriers)
     }
     auto &&kk = pinned_for<M, (MT && SameType<P, Exact>::value)>(k);
     const int lane = threadIdx.x & 63;
@@ -808,7 +809,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         // tile's own word goes up — and nobody waits for the slowest strip twice.
         {
             unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(&mt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) old = __hip_atomic_fetch_add(&mt_arrive[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             old = __builtin_amdgcn_readfirstlane(old);
             if (old + 1u == (unsigned)NW * ((unsigned)tick + 1u) && lane == 0) {
                 __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -881,8 +882,12 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                         // started from (fibhip.hip, `recover`); launches queued behind it find the word and leave at their first
                         // boundary without writing anything
                         unsigned expected = 0u;
-                        __hip_atomic_compare_exchange_strong(mt.err, &expected, mt.ticks_id >> 16, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
+                        if (__hip_atomic_compare_exchange_strong(mt.err, &expected, mt.ticks_id >> 16, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT))
+                            // ... and tells the host in ITS memory (page-locked, behind the host's own word): a synchronising
+                            // call then reads a word of host memory instead of copying one from the device behind every launch
+                            __hip_atomic_store(mt.snap_flag + MT_HOST_WORD_AT + MT_GIVEUP_WORD, mt.ticks_id >> 16, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
                         mt_abort = 1;
                     }
                     break;

@@ -18,10 +18,16 @@ class Fenton4v(IonicModel):
         self.max_v = 1.0
         self.depol = 0.0
 
-    def define(self, s1=True):
+    def define(self, s1=True, state=None):
         """initial conditions u=0, v=1, w=1, s=0 and the S1 stimulus column u[:,1]=1
-        (fenton.py:116-123); one tick = 10 fused sub-steps (fenton.py:133-138)"""
+        (fenton.py:116-123); one tick = 10 fused sub-steps (fenton.py:133-138).
+        state: resume from a dict U/V/W/S -> [H,W] array instead (what `run(keep_state=True)` leaves in
+        `model.state`; the reference offers this for Courtemanche only, court.py:87-89 — same contract here)"""
         super().define()
+        if state is not None:
+            self._create(self._resume_arrays(state))
+            self._U = self._State['U']
+            return
         shape = [self.height, self.width]
         u_init = np.zeros(shape, dtype=np.float32)
         v_init = np.ones(shape, dtype=np.float32)

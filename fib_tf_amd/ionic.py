@@ -246,6 +246,20 @@ class IonicModel:
     def _configure_stepper(self, st):
         """model-specific constants (BeelerReuter: the Chebyshev table)"""
 
+    def _resume_arrays(self, state):
+        """`define(state=...)`: a dict name -> [H, W] array — what `run(keep_state=True)` leaves in `model.state`
+        (ionic.py:226-229; court.py:87-89, 623-626 resumes from it) — as the model's arrays in variable order"""
+        missing = [n for n in self.VAR_NAMES if n not in state]
+        if missing:
+            raise KeyError('define(state=...): missing state variables %s' % missing)
+        out = []
+        for n in self.VAR_NAMES:
+            a = np.asarray(state[n], dtype=np.float32)
+            if a.shape != (self.height, self.width):
+                raise ValueError('define(state=...): %s has shape %s, the grid is %s' % (n, a.shape, (self.height, self.width)))
+            out.append(a)
+        return out
+
     def _create(self, init_arrays, steps_per_tick=0):
         """init_arrays: list of [H,W] float32 in the model's variable order"""
         if self._stepper is not None:

@@ -321,7 +321,8 @@ typedef struct fibhip_trace_event {
     int K, tile_w, tile_h, rows_per_wave, ticks;
 } fibhip_trace_event;
 int fibhip_trace_begin(fibhip_t h);
-int fibhip_trace_end(fibhip_t h, fibhip_trace_event *out, int max_events);   /* returns the number of events */
+int fibhip_trace_end(fibhip_t h, fibhip_trace_event *out, int max_events);   /* returns the number of events traced; the first */
+                                                                              /* max_events of them are written (more = truncated) */
 
 const char *fibhip_last_error(void);
 

@@ -23,18 +23,69 @@ def advance(m, ticks, hook=None):
             hook(i)
 
 
-def test_fenton_512_config1_vs_oracle(gpu_lib, orc):
-    """fenton.py __main__ (fenton.py:156-171): 512x512, diff 1.5, hole (256,256,30), S1; 1000 sub-steps"""
+# Tolerances of the full-size oracle comparisons: at most ten times what the GPU measures on these very runs (every test prints
+# its measured figures; DESIGN.md 3 lists them), so that a regression of the kernels that run at BASELINE's sizes — the
+# multi-tick launches, their stop / run-ahead paths — is caught HERE, where they meet the checker, and not only by the
+# bit-identity tests against one launch per tick.  The runs include the S2 stimulus: the broken wave it leaves amplifies rounding
+# differences far more than the plane S1 wave does (a run without S2 ends 1000 sub-steps at 4e-7), and under the fast policy a few
+# cells sit on the other side of one of the model's Heaviside switches for a step (fenton.py:73-79,87: V jumps by dt*V/tau) —
+# hence a bound on the bulk (99.99th percentile) next to the bound on the worst cell there.
+FENTON_500_TOL = {'fast': 4e-5, 'exact': 5e-6}            # 200 sub-steps after S2.  measured: 4.2e-6 / 5.1e-7
+FENTON_1000_TOL = {'fast': 0.1, 'exact': 4e-4}            # worst cell, 700 sub-steps after S2.  measured: 2.3e-2 / 4.1e-5
+FENTON_1000_BULK = {'fast': 2e-3, 'exact': 2e-4}          # 99.99th percentile.  measured: 2.2e-4 / 2.1e-5
+BR_100_TOL_MV = {'fast': 4e-3, 'exact': 2.5e-4}           # 100 sub-steps with S2.  measured: 7.7e-4 mV / 2.3e-5 mV
+BR_100_TOL_GATE = {'fast': 1.6e-4, 'exact': 5e-6}         # measured: 1.6e-5 / 4.8e-7
+COURT_21_TOL_MV = {'fast': 2e-3, 'exact': 2e-3}           # 21 ticks with three 'slow' ops.  measured: 2.0e-4 mV / 2.1e-4 mV
+COURT_21_TOL_REL = {'fast': 1e-4, 'exact': 1e-4}          # worst array (the SR release gate u, court.py:243): 1.5e-5 of its range
+
+
+def pace_rect_luq(H, W):
+    return 1, H // 2, 1, W // 2                           # ionic.py:152
+
+
+def err_report(got, ref, tol):
+    """(max |d|, values beyond tol, values beyond 10 tol, text) — the text goes into every assertion message"""
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    n1, n10 = int((d > tol).sum()), int((d > 10 * tol).sum())
+    return float(d.max()), n1, n10, 'max %.3g, %d of %d values beyond %.1g, %d beyond %.1g, 99.99th percentile %.3g' % (
+        d.max(), n1, d.size, tol, n10, 10 * tol, np.percentile(d, 99.99))
+
+
+@pytest.mark.parametrize('policy', ['fast', 'exact'])
+def test_fenton_512_config1_vs_oracle(gpu_lib, orc, policy):
+    """fenton.py __main__ (fenton.py:156-187): 512x512, diff 1.5, hole (256,256,30), S1, S2 'luq' fired in mid-run, a frame
+    read back in mid-run (image(): the run-ahead / stop path of the multi-tick launches); 1000 sub-steps"""
     from fib_tf_amd.fenton import Fenton4v
-    m = Fenton4v(dict(BASE, height=512, width=512, diff=1.5))
+    m = Fenton4v(dict(BASE, height=512, width=512, diff=1.5, fast_math=policy == 'fast'))
     m.add_hole_to_phase_field(256, 256, 30)
     m.define()
+    m.add_pace_op('s2', 'luq', 1.0)
     ref = state(m)
-    advance(m, 100)
-    orc.fenton_run(ref, 0.1, 1.5, m.phase, 1000)
+    frames = {}
+
+    def hook(i):
+        if i == 29:
+            m.fire_op('s2')
+        if i in (49, 59, 69):
+            frames[i] = m.image().copy()
+    advance(m, 100, hook)
+    assert m._stepper.ticks_per_launch() > 1              # this IS the multi-tick path
+    # the oracle: the same ticks, S2 after tick 29 (fire_op follows the tick's sess.run, fenton.py:181-183)
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 300)
+    r0, r1, c0, c1 = pace_rect_luq(512, 512)
+    ref[0] = orc.pace(ref[0], r0, r1, c0, c1, 1.0, 0.0)
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 200)
+    mid = ref[0].copy()
+    orc.fenton_run(ref, 0.1, 1.5, m.phase, 500)
     got = state(m)
-    err = np.abs(got.astype(np.float64) - ref).max()
-    assert err <= 1e-3, err                       # tolerance stated for 1000 sub-steps; measured ~4e-7
+    err, n1, n10, text = err_report(got, ref, FENTON_1000_BULK[policy])
+    err_mid, m1, m10, text_mid = err_report(frames[49], mid, FENTON_500_TOL[policy])
+    bulk = float(np.percentile(np.abs(got.astype(np.float64) - ref), 99.99))
+    print('fenton 512 %s: final state %s; frame after 500 sub-steps %s' % (policy, text, text_mid))
+    assert err_mid <= FENTON_500_TOL[policy], 'frame after 500 sub-steps: ' + text_mid
+    assert bulk <= FENTON_1000_BULK[policy], 'after 1000 sub-steps: ' + text
+    assert err <= FENTON_1000_TOL[policy], 'after 1000 sub-steps: ' + text
+    assert got[0].max() > 0.9 and frames[69][r0 + 5, c0 + 5] > 0.5            # the S2 stimulus is really there
 
 
 @pytest.mark.parametrize('policy', ['fast', 'exact'])
@@ -120,24 +171,48 @@ def test_fenton_mirror_symmetry_1024(gpu_lib):
     assert s[0].max() > 0.9                       # the S1 wave is really travelling
 
 
-def test_br_512_config2_vs_oracle(gpu_lib, orc):
-    """br.py __main__ (br.py:348-365): 512x512, diff 0.809, cheby=True, hole (150,200,40); 100 sub-steps"""
+@pytest.mark.parametrize('policy', ['fast', 'exact'])
+def test_br_512_config2_vs_oracle(gpu_lib, orc, policy):
+    """br.py __main__ (br.py:348-365): 512x512, diff 0.809, cheby=True, hole (150,200,40), S2 'luq' and a read-back in
+    mid-run; 100 sub-steps"""
     from fib_tf_amd.br import BeelerReuter
-    m = BeelerReuter(dict(BASE, height=512, width=512, diff=0.809))
+    m = BeelerReuter(dict(BASE, height=512, width=512, diff=0.809, fast_math=policy == 'fast'))
     m.add_hole_to_phase_field(150, 200, 40)
     m.define()
+    m.add_pace_op('s2', 'luq', 10.0)
     ref = state(m)
-    advance(m, 20)
-    orc.br_run(ref, 0.1, 0.809, m.phase, m.chebyshev_table().astype(np.float32), False, 20)
+    frames = {}
+
+    def hook(i):
+        if i == 7:
+            m.fire_op('s2')
+        if i in (11, 15):
+            frames[i] = m.pot().eval().copy()
+    advance(m, 20, hook)
+    assert m._stepper.ticks_per_launch() > 1
+    tbl = m.chebyshev_table().astype(np.float32)
+    orc.br_run(ref, 0.1, 0.809, m.phase, tbl, False, 8)
+    r0, r1, c0, c1 = pace_rect_luq(512, 512)
+    ref[0] = orc.pace(ref[0], r0, r1, c0, c1, 10.0, -90.0)
+    orc.br_run(ref, 0.1, 0.809, m.phase, tbl, False, 4)
+    mid = ref[0].copy()
+    orc.br_run(ref, 0.1, 0.809, m.phase, tbl, False, 8)
     got = state(m)
-    assert np.abs(got[0].astype(np.float64) - ref[0]).max() <= 2e-5 * 120.0
-    assert np.abs(got[2:].astype(np.float64) - ref[2:]).max() <= 2e-5
+    ev = np.abs(got[0].astype(np.float64) - ref[0]).max()
+    eg = np.abs(got[2:].astype(np.float64) - ref[2:]).max()
+    em = np.abs(frames[11].astype(np.float64) - mid).max()
+    print('br 512 %s: |dV| %.3g mV after 100 sub-steps, %.3g mV after 60, gates %.3g' % (policy, ev, em, eg))
+    assert ev <= BR_100_TOL_MV[policy], 'max |dV| after 100 sub-steps: %.3g mV (tolerance %.1g)' % (ev, BR_100_TOL_MV[policy])
+    assert em <= BR_100_TOL_MV[policy], 'frame after 60 sub-steps: %.3g mV' % em
+    assert eg <= BR_100_TOL_GATE[policy], 'gates: %.3g (tolerance %.1g)' % (eg, BR_100_TOL_GATE[policy])
+    assert got[0][r0 + 5, c0 + 5] > -20.0                 # the stimulated quadrant is depolarised
 
 
-def test_court_1024_config4_vs_oracle(gpu_lib, orc):
+@pytest.mark.parametrize('policy', ['fast', 'exact'])
+def test_court_1024_config4_vs_oracle(gpu_lib, orc, policy):
     """court.py protocol scaled x2: 1024x1024, two holes, fast tick + 'slow' every 10th"""
     from fib_tf_amd.court import Courtemanche
-    m = Courtemanche(dict(BASE, height=1024, width=1024, diff=0.809))
+    m = Courtemanche(dict(BASE, height=1024, width=1024, diff=0.809, fast_math=policy == 'fast'))
     m.add_hole_to_phase_field(512, 512, 60)
     m.add_hole_to_phase_field(512, 512, 500, neg=True)
     m.define()
@@ -145,10 +220,14 @@ def test_court_1024_config4_vs_oracle(gpu_lib, orc):
     advance(m, 21, lambda i: m.fire_op('slow') if i % 10 == 0 else None)
     orc.court_run(ref, 0.1, 0.809, m.phase, True, 0, 21)
     got = state(m)
-    assert np.abs(got[0].astype(np.float64) - ref[0]).max() <= 2e-5 * 150.0
+    ev = np.abs(got[0].astype(np.float64) - ref[0]).max()
+    assert ev <= COURT_21_TOL_MV[policy], 'max |dV| after 21 ticks: %.3g mV (tolerance %.1g)' % (ev, COURT_21_TOL_MV[policy])
+    worst = (0.0, '')
     for i in range(1, 21):
         sc = max(float(np.abs(ref[i]).max()), 1e-3)
-        assert np.abs(got[i].astype(np.float64) - ref[i]).max() <= 2e-5 * sc, m.VAR_NAMES[i]
+        worst = max(worst, (float(np.abs(got[i].astype(np.float64) - ref[i]).max()) / sc, m.VAR_NAMES[i]))
+    print('court 1024 %s: |dV| %.3g mV after 21 ticks, worst array %s %.3g of its range' % (policy, ev, worst[1], worst[0]))
+    assert worst[0] <= COURT_21_TOL_REL[policy], 'worst array %s: %.3g of its range (tolerance %.1g)' % (worst[1], worst[0], COURT_21_TOL_REL[policy])
 
 
 def test_court_1024_ticks_per_launch_invariance(gpu_lib, monkeypatch):

@@ -1112,6 +1112,43 @@ def test_court_keep_state_and_resume(gpu_lib):
         assert np.array_equal(m2._State[k].eval(), m1.state[k])
 
 
+@pytest.mark.parametrize('model', ['fenton', 'br'])
+def test_keep_state_and_resume_every_model(gpu_lib, model):
+    """run(keep_state=True) -> model.state -> define(state=...) for the models whose reference `define` cannot resume
+    (fenton.py:110, br.py:64 take s1 only; SURVEY 5 asks for it for all): a run cut in two at a tick boundary and resumed from
+    the kept state ends in the bits of the uncut run"""
+    from fib_tf_amd.fenton import Fenton4v
+    from fib_tf_amd.br import BeelerReuter
+    cls, diff = (Fenton4v, 1.1) if model == 'fenton' else (BeelerReuter, 0.809)
+    spt = 10 if model == 'fenton' else 5
+
+    def make(ticks):
+        m = cls(dict(cfg(45, 70, diff), duration=ticks * spt * 0.1 + 1e-9))
+        m.add_hole_to_phase_field(30, 20, 7)
+        return m
+    whole = make(14)
+    whole.define()
+    for _ in whole.run(keep_state=True):
+        pass
+    first = make(6)
+    first.define()
+    for _ in first.run(keep_state=True):
+        pass
+    assert set(first.state) == set(first.VAR_NAMES)
+    second = make(8)
+    second.define(state=first.state)
+    for k in first.VAR_NAMES:
+        assert np.array_equal(second._State[k].eval(), first.state[k])
+    for _ in second.run(keep_state=True):
+        pass
+    for k in whole.VAR_NAMES:
+        assert np.array_equal(second.state[k], whole.state[k]), k
+    with pytest.raises(KeyError):
+        make(1).define(state={'V': first.state[first.VAR_NAMES[0]]})
+    with pytest.raises(ValueError):
+        make(1).define(state={k: v[:-1] for k, v in first.state.items()})
+
+
 # --------------------------------------------------------------------------------------------
 # oracle comparisons on seeded inputs at sizes the oracle finishes in seconds
 # --------------------------------------------------------------------------------------------
