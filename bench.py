@@ -243,6 +243,8 @@ def driver_loop(m, st, s2, court):
         tick = state['tick']
         if not snap:
             st.expect(n)                              # as run() does without a screen: the whole loop is one series
+        else:                                         # with frames: the ticks up to the first one (run(im) knows its period)
+            st.expect(min(n, (-tick) % ds + 1))
         for k in range(n):
             st.step(1)
             if court and tick % 10 == 0:

@@ -190,6 +190,23 @@ static FIB_DEV float tanh_rf(float x)
     return __builtin_copysignf(res, x);
 }
 
+// 1 + tanh(x) for the rounding-faithful policy, where the reference forms exactly that sum (fenton.py:83 `1 + tanh(..)`, :90
+// `0.5*(1 + tanh(..))`): 2 - 2/(e^{2x} + 1), e by exp_core, the quotient by v_rcp_f32 + one Newton step, the last step ONE fused
+// multiply-add.  What the sum needs of tanh is ABSOLUTE accuracy — it lives in [0, 2], and RN(1 + t) throws away whatever
+// relative accuracy a small t had — so tanh's polynomial branch for small arguments (there for the RELATIVE accuracy of tanh
+// alone) and the select between the two branches are dead weight here: 13 instructions instead of 25.  Measured on the device
+// against double precision (tools/ubench/acc_rf.hip, 22 M arguments per sign): see profiles/r04_accuracy_one_plus_tanh.txt —
+// the error of the sum is within that of 1.0f + tanh_rf(x), whose tanh is itself within 1.5 ulp.
+static FIB_DEV float one_plus_tanh_rf(float x)
+{
+    const float y = 2.0f * __builtin_amdgcn_fmed3f(x, -50.0f, 10.0f);   // 1 + tanh rounds to 0 / 2 beyond; keeps e finite and > 0 paths exact
+    const float e = exp_core(y);
+    const float d = e + 1.0f;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(-2.0f, r, 2.0f);
+}
+
 struct Exact {
     // a*b + c: the reference rounds the product and the sum separately
     template <class T, class B, class C>
@@ -205,10 +222,15 @@ struct Exact {
     template <class T>
     static FIB_DEV T tanhv(const T &a) { return vmap(a, [](float x) { return tanh_rf(x); }); }
     // 1 + tanh(a) and 0.5*(1 + tanh(a)) - s, as the reference writes them (fenton.py:83,90)
+#ifdef FIB_EXACT_TANH_SUM_VIA_TANH                 // (the form before round 4: the sum through the stand-alone tanh; A/B builds only)
     template <class T>
     static FIB_DEV T one_plus_tanh(const T &a) { return 1.0f + tanhv(a); }
+#else
     template <class T>
-    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return (1.0f + tanhv(a)) * 0.5f + (-s); }
+    static FIB_DEV T one_plus_tanh(const T &a) { return vmap(a, [](float x) { return one_plus_tanh_rf(x); }); }
+#endif
+    template <class T>
+    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return one_plus_tanh(a) * 0.5f + (-s); }
     template <class A, class T>
     static FIB_DEV T div(const A &a, const T &b) { return vzip(a, b, [](float x, float y) { return x / y; }); }
     template <class T> static FIB_DEV T rcp(const T &a) { return vmap(a, [](float x) { return 1.0f / x; }); }
