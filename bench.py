@@ -42,7 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # rocprofv3 --pmc passes of this command, condensed by tools/prof_summary.py (PMC cannot run inside the bench)
-COUNTERS_JSON = [os.path.join(ROOT, 'profiles', 'counters_r03.json'), os.path.join(ROOT, 'profiles', 'counters_r02.json'),
+COUNTERS_JSON = [os.path.join(ROOT, 'profiles', 'counters_r04.json'), os.path.join(ROOT, 'profiles', 'counters_r03.json'), os.path.join(ROOT, 'profiles', 'counters_r02.json'),
                  os.path.join(ROOT, 'profiles', 'traffic_r01.json')]
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32; max shader clock (MI355X_MICROARCH.md, chip-level parameters)
