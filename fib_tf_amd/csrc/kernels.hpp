@@ -458,6 +458,9 @@ struct MtArgs {
 #ifndef FIB_B_LASTWAVE
 #define FIB_B_LASTWAVE 0
 #endif
+#ifndef FIB_B_INBOX
+#define FIB_B_INBOX 0
+#endif
 constexpr int MT_SNAP_STRIDE = 16;                    // words between two tiles' words in snap_flag
 constexpr int MT_MAX_TILES = 1024;                    // epoch / snap words allocated per handle (only grids of <= ncu tiles use them)
 constexpr int MT_HOST_WORD_AT = MT_MAX_TILES * MT_SNAP_STRIDE;   // the host's word, in words from snap_flag
@@ -822,8 +825,23 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #else
         __syncthreads();
         FIB_BSTAMP(3);
+#if FIB_B_INBOX
+        // PUSH instead of pull: the tile writes its tick count into a word of each neighbour's OWN line (slot = the direction it
+        // is seen from), so that a tile polls ONE 64-byte line — eight neighbours in one memory request — instead of eight lines
+        // on eight channels
+        if (wave == 0 && lane < 8) {
+            const int tiles_y = g.ntiles / g.tiles_x;
+            const int d = lane < 4 ? lane : lane + 1;
+            const int ny = by + d / 3 - 1, nx = bx + d % 3 - 1;
+            const int od = 8 - d, slot = od < 4 ? od : od - 1;     // the direction this tile lies in, seen from that neighbour
+            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < g.tiles_x)
+                __hip_atomic_store(mt.epoch + (size_t)(ny * g.tiles_x + nx) * MT_EPOCH_STRIDE + slot, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         if (threadIdx.x == 0) {
+#if !FIB_B_INBOX
             __hip_atomic_store(mt.epoch + (size_t)tile * MT_EPOCH_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             // every wave's write-through stores to the host frame have been acknowledged (vmcnt(0) before the barrier above):
             // the word follows them
             if (tick == snap_at) {
@@ -851,8 +869,13 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                 if ((hws >> 16) == (mt.ticks_id >> 16) && lane == 0)
                     __hip_atomic_store(mt.err + MT_EPOCH_STRIDE, hws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#if FIB_B_INBOX
+            const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
+                                                                : mt.epoch + (size_t)tile * MT_EPOCH_STRIDE + (lane & 7));
+#else
             const unsigned *f = lane == 8 ? mt.err : (lane == 9 ? mt.err + MT_EPOCH_STRIDE
                                                                 : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE);
+#endif
             const unsigned done = (unsigned)tick + 1u;
             const unsigned wait_ms = (unsigned)mt.snap_var >> 8;
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (wait_ms ? (unsigned long long)wait_ms * 100000ull : MT_WAIT_TICKS);
