@@ -962,6 +962,13 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         h->mt_max = (e && atoi(e) == 0) ? 1 : (em && atoi(em) > 0 ? imin(atoi(em), 4096) : MT_MAX_TICKS);
         if (interleaved || desc->ghost_top || desc->ghost_bottom || (long long)h->cells * ((nv + 3) / 4 * 4) * 8 >= (1LL << 31))
             h->mt_max = 1;
+        // a process-wide CU mask takes compute units away that multiProcessorCount still reports: the tiles of a grid
+        // "that fits" would then not all be resident (a launch would give up after its bound and the handle fall back, §2d of
+        // DESIGN.md — correct, but two seconds late): never start
+        for (const char *var : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK"}) {
+            const char *m = getenv(var);
+            if (m && *m) h->mt_max = 1;
+        }
     }
     h->agg = nullptr;
     h->use_agg = false;

@@ -512,7 +512,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr unsigned WMASK = M::mask(MODE);
     __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
-    __shared__ unsigned mt_arrive[FIB_B_LASTWAVE ? 1 : 0 + 1];      // (FIB_B_LASTWAVE, measured and not taken: waves whose stores have been acknowledged)
+    __shared__ unsigned mt_arrive[1];                               // (FIB_B_LASTWAVE, measured and not taken: waves whose stores have been acknowledged)
     __shared__ float snapl[MT ? NW * R * 64 : 1];                    // multi-tick launches: the frame's values, parked for one tick
 
     const int tile = xcd_tile(blockIdx.x, g.ntiles);

@@ -110,6 +110,25 @@ def test_wait_bound_is_a_property_of_the_handle(gpu_lib, monkeypatch):
     st.close()
 
 
+def test_no_multi_tick_launches_under_a_cu_mask(gpu_lib, monkeypatch):
+    """a process-wide CU mask takes compute units away that the device still reports: the tiles of a grid 'that fits' would not
+    all be resident, so such a process never starts a multi-tick launch (it would give up after its bound and fall back)"""
+    monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+    monkeypatch.delenv('FIBHIP_MT', raising=False)
+    init, phi = _state(96, 100, 3)
+    for var in ('HSA_CU_MASK', 'ROC_GLOBAL_CU_MASK'):
+        monkeypatch.setenv(var, '0:0-127')            # (read by this library at create; the runtime of this process is up already)
+        st = gpu_lib.Stepper(gpu_lib.FENTON4V, 96, 100, 0.1, 1.3, flags=gpu_lib.FAST)
+        st.set_state(-1, init)
+        st.step(3)
+        assert st.ticks_per_launch() == 1 and st.launch_stats()['mt_launches'] == 0
+        st.close()
+        monkeypatch.delenv(var)
+    st = gpu_lib.Stepper(gpu_lib.FENTON4V, 96, 100, 0.1, 1.3, flags=gpu_lib.FAST)
+    assert st.ticks_per_launch() > 1
+    st.close()
+
+
 @pytest.mark.parametrize('H,W,variant', [(96, 100, '10,44,25,-3'), (512, 512, None)])
 def test_a_declared_series_is_one_launch_from_the_first_time(gpu_lib, monkeypatch, H, W, variant):
     """fibhip_expect(n): the caller says how many ticks it will ask for before it looks again (IonicModel.run() does, from its
