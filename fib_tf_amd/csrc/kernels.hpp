@@ -396,7 +396,16 @@ __device__ unsigned long long fib_bstamps[4096 * 16];
             fib_bstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define FIB_BSTAMP_WAIT() __builtin_amdgcn_s_waitcnt(0x0070)      /* vmcnt(0) lgkmcnt(0): the phase's loads have landed */
+// (round 4: when a wave ARRIVES at the barrier of a sub-step — arithmetic done, new potential written — against FIB_STAMP's
+// "barrier passed and next window read": what a sub-step spends computing and what it spends waiting)
+__device__ unsigned long long fib_wstamps[4096 * 16];
+#define FIB_WSTAMP(slot)                                                                         \
+    do {                                                                                         \
+        if ((threadIdx.x & 63) == 0 && (slot) < 16)                                              \
+            fib_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
+#define FIB_WSTAMP(slot) do { } while (0)
 #define FIB_STAMP(slot) do { } while (0)
 #define FIB_BSTAMP(slot) do { } while (0)
 #define FIB_BSTAMP_WAIT() do { } while (0)
@@ -452,6 +461,8 @@ struct MtArgs {
     int snap_var;         // low byte: which array the frame is; the other three: the bound on a tile's wait for its neighbours in
                           // milliseconds (0 = MT_WAIT_TICKS; packed, not an argument of its own: see ticks_id)
 };
+#define FIB_STR2(x) #x
+#define FIB_STR(x) FIB_STR2(x)
 #ifndef FIB_POLL_SLEEP
 #define FIB_POLL_SLEEP 1
 #endif
@@ -468,6 +479,21 @@ constexpr int MT_GIVEUP_WORD = 8;                     // ... and, this many word
 constexpr int MT_EPOCH_STRIDE = 64;                   // words (256 bytes)
 constexpr unsigned MT_CANCEL = 0xFFFFu;               // the host's word, low half: this launch is not wanted any more
 constexpr unsigned long long MT_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
+constexpr int MT_WAIT_SHIFT = 17;                            // MtArgs::snap_var's upper three bytes count 2^17 such ticks (1.31 ms)
+// The multi-tick kernels sit at their register limits (Fenton: 128 vector registers, and scalar registers spilled into vector
+// lanes): an edit ANYWHERE in them — one `& 0xFF` in the prologue — re-draws the register allocation and moves the kernel by 2-3 %
+// (round 4, tools/r04_h.sh -> profiles/r04_ab_kernel_variants.txt: round 3's text 12.28 us per tick, the same with the give-up
+// word set by compare-and-swap 12.60, by a plain store 12.29, the wait bound as a shift 12.60 or 12.24 depending on what else is
+// in, ...).  These switches keep the equivalent forms that were measured; the defaults are the combination that lost nothing
+// against round 3's kernel for Fenton (12.32 / 12.28) and is the fastest measured for the other two (rounding-faithful Fenton 18.8
+// against 21.5, Beeler-Reuter 15.36 against 15.75).
+#ifndef FIB_WAIT_FORM
+#define FIB_WAIT_FORM 0     // the wait bound: 0 = milliseconds in MtArgs::snap_var's upper bytes (0: MT_WAIT_TICKS), 1 = units of 2^17 ticks, 2 = MT_WAIT_TICKS
+#endif
+#ifndef FIB_GIVEUP_CAS
+#define FIB_GIVEUP_CAS 0    // the give-up word: a plain store of the launch's id (every tile of a launch writes the same id, and a launch
+                            // queued behind one that gave up finds the word before its own wait can run out) / compare-and-swap
+#endif
 
 typedef unsigned fib_v4u __attribute__((ext_vector_type(4)));
 typedef float fib_v4f __attribute__((ext_vector_type(4)));
@@ -510,7 +536,19 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr int NW = (CY + R - 1) / R;
     constexpr int LP = 64, LQ = NW * R + 2, NL = LP * LQ;
     constexpr unsigned WMASK = M::mask(MODE);
-    __shared__ float lds[2][NL + (R + 4) * 64];                     // (+ spare rows: see `wi`)
+    // The LDS image of the potential.  Strips of an ODD number of rows: row-major, one dword per cell, the 3 x (R+2) window read
+    // as ds_read_b32.  Strips of an EVEN number of rows (round 4): rows 2k and 2k+1 of a column form one aligned 8-byte word —
+    // element (row, col) at dword (row >> 1) * 128 + 2 col + (row & 1) — and the window, which then starts on an even row and has an
+    // even number of rows, is read as 3 x (R+2)/2 ds_read_b64.  The LDS array serves a wave's ds_read_b64 in the two cycles it takes
+    // for a ds_read_b32 (MI355X_MICROARCH.md, LDS: 256 against 128 B/clk), and the window reload of ALL waves at once, right behind
+    // a sub-step's barrier, is LDS-bandwidth time on everybody's critical path (stamped build, profiles/r04_stamps_substeps.txt:
+    // the LAST wave to reach the barrier still waits 450-560 cycles for its window — 15 waves x 15 dwords x 2 cycles).
+    // Beeler-Reuter's two-row strips: 15.4 -> 15.1 us per tick.  Three-row strips would need two copies of the tile program (a
+    // window starts on an even row in every other wave only): built and measured — the registers it costs the Fenton kernel, which
+    // sits at its 128, outweigh the LDS cycles (12.3 -> 13.0 us per tick; four-row strips with the paired image: 13.8).
+    constexpr bool PAIR = (R % 2 == 0);
+    constexpr int SPARE = PAIR ? R + 6 : R + 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][NL + SPARE * 64];   // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
     __shared__ unsigned mt_arrive[1];                               // (FIB_B_LASTWAVE, measured and not taken: waves whose stores have been acknowledged)
     __shared__ float snapl[MT ? NW * R * 64 : 1];                    // multi-tick launches: the frame's values, parked for one tick
@@ -589,7 +627,11 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             for (int r = 0; r < R; ++r) {
                 float x = s[r][0];
 #pragma unroll
+#if FIB_WAIT_FORM == 2
+                for (int v = 1; v < NV; ++v) x = mt.snap_var == v ? s[r][v] : x;
+#else
                 for (int v = 1; v < NV; ++v) x = (mt.snap_var & 0xFF) == v ? s[r][v] : x;
+#endif
                 snapl[(c0 + r) * 64 + lane] = x;                    // (read back by the same thread: no barrier needed)
             }
         }
@@ -597,7 +639,41 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // rows of the compute box that can still be correct at sub-step st: [lo0+st.., hi0-st..) unless
     // the box reaches the domain edge on that side (no staleness enters through a real boundary)
     const bool top_open = cy0 + g.row_off > 0, bot_open = cy0 + CY + g.row_off < g.Hg;
-    const int aW = c0 * LP + jW, aC = c0 * LP + jC, aE = c0 * LP + jE;   // window addresses of this strip
+    // window addresses of this strip (paired image: of the 8-byte word that holds its first two rows)
+    const int aW = PAIR ? (c0 >> 1) * 128 + 2 * jW : c0 * LP + jW, aC = PAIR ? (c0 >> 1) * 128 + 2 * jC : c0 * LP + jC,
+              aE = PAIR ? (c0 >> 1) * 128 + 2 * jE : c0 * LP + jE;
+    // dword offset of the row k rows below a strip's first row (tile row c0 + 1: always odd in the paired image), from that row's
+    // address as `cell_at` gives it (paired image: the address of the row's 8-byte word)
+    auto ro = [](int k) constexpr { return PAIR ? ((1 + k) >> 1) * 128 + ((1 + k) & 1) : k * LP; };
+    auto cell_at = [](int row, int col) { return PAIR ? (row >> 1) * 128 + 2 * col : row * LP + col; };
+    constexpr int SPARE_ROW = PAIR ? LQ + 3 : LQ + 2;                    // a strip's worth of rows nobody reads, behind the tile
+    auto window = [&](const float *Bq, float (&w)[R + 2][3]) {          // the strip's 3 x (R+2) window out of the image Bq
+        if constexpr (PAIR) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int m = 0; m < (R + 2) / 2; ++m) {
+                // (the second and later words of a column from addresses the compiler cannot relate to the first: it would fuse
+                // two reads into one ds_read2st64_b64, which the LDS serves in 8 cycles where two ds_read_b64 take 4)
+                int oW = aW + m * 128, oC = aC + m * 128, oE = aE + m * 128;
+                if (m > 0) asm volatile("" : "+v"(oW));
+                const v2f a = *reinterpret_cast<const v2f *>(Bq + oW);
+                if (m > 0) asm volatile("" : "+v"(oC));
+                const v2f b = *reinterpret_cast<const v2f *>(Bq + oC);
+                if (m > 0) asm volatile("" : "+v"(oE));
+                const v2f c = *reinterpret_cast<const v2f *>(Bq + oE);
+                w[2 * m][0] = a.x; w[2 * m + 1][0] = a.y;
+                w[2 * m][1] = b.x; w[2 * m + 1][1] = b.y;
+                w[2 * m][2] = c.x; w[2 * m + 1][2] = c.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R + 2; ++q) {
+                w[q][0] = Bq[aW + q * LP];
+                w[q][1] = Bq[aC + q * LP];
+                w[q][2] = Bq[aE + q * LP];
+            }
+        }
+    };
     // ---- everything about the strip's rows that does not change from sub-step to sub-step, as wave-uniform scalars
     // (the step loop then spends its scalar instructions on two min/max and a few bit tests)
     const int g0 = cy0 + c0 + g.row_off;                            // global row of the strip's first row
@@ -614,7 +690,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     }
     // lanes whose cells nobody taps write to spare rows behind the tile instead of being masked out (row offsets
     // -2 .. R+1 are applied to this address)
-    const int wi = wr ? (c0 + 1) * LP + lane : NL + 2 * LP + lane;
+    const int wi = wr ? cell_at(c0 + 1, lane) : cell_at(SPARE_ROW, lane);
     FIB_STAMP(1);
     // all prologue loads are consumed by the first sub-step anyway: drain them once here, so that the
     // compiler does not carry per-use `s_waitcnt vmcnt(n)` into every iteration of the step loop
@@ -643,6 +719,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     constexpr bool WHOLE_LOOP = MT && NV * R <= FIB_WHOLE_NVR;
     const bool whole = WHOLE_LOOP && ra_fix == 0 && rb_fix == R && (!top_open || c0 >= K - 1) && (!bot_open || c0 + R <= CY - (K - 1)) &&
                        pub == (1u << R) - 1u && top_r < 0 && bot_r < 0;
+#ifdef FIB_LOOP_ALIGN           // (experiment: does the placement of the tick loop in the instruction stream matter?)
+    asm volatile(".p2align " FIB_STR(FIB_LOOP_ALIGN));
+#endif
 #pragma unroll 1
     for (int tick = 0;; ++tick) {
     // the host's word is read over PCIe by ONE thread of the grid at the START of a tick and looked at at the tick's end: the
@@ -687,17 +766,13 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             }
             if (st + 1 < K) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) B[wi + r * LP] = s[r][0];
+                for (int r = 0; r < R; ++r) B[wi + ro(r)] = s[r][0];
+                FIB_WSTAMP(st);
 #ifndef FIB_DIAG_NO_BARRIER
                 __syncthreads();
 #endif
 #ifndef FIB_DIAG_NO_RELOAD
-#pragma unroll
-                for (int q = 0; q < R + 2; ++q) {
-                    win[q][0] = B[aW + q * LP];
-                    win[q][1] = B[aC + q * LP];
-                    win[q][2] = B[aE + q * LP];
-                }
+                window(B, win);
 #endif
             }
             FIB_STAMP(3 + st);
@@ -747,32 +822,28 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
             const unsigned m = live & pub;
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if ((m >> r) & 1u) B[wi + r * LP] = s[r][0];        // wave-uniform branch, no lane mask
+                if ((m >> r) & 1u) B[wi + ro(r)] = s[r][0];         // wave-uniform branch, no lane mask
             if (top_r >= 0 || bot_r >= 0) {                         // a strip that holds the grid's row 1 or H-2
                 // enforce_boundary + REFLECT: the border and ghost rows above row 1 / below row H-2 take its new value
                 // (the columns need nothing: their clamp is in the tap addresses)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (r == top_r && ((live >> r) & 1u)) {
-                        B[wi + (r - 1) * LP] = s[r][0];
-                        if (c0 + r >= 1) B[wi + (r - 2) * LP] = s[r][0];
+                        B[wi + ro(r - 1)] = s[r][0];
+                        if (c0 + r >= 1) B[wi + ro(r - 2)] = s[r][0];
                     }
                     if (r == bot_r && ((live >> r) & 1u)) {
-                        B[wi + (r + 1) * LP] = s[r][0];
-                        if (c0 + r + 1 < LQ - 2) B[wi + (r + 2) * LP] = s[r][0];
+                        B[wi + ro(r + 1)] = s[r][0];
+                        if (c0 + r + 1 < LQ - 2) B[wi + ro(r + 2)] = s[r][0];
                     }
                 }
             }
+            FIB_WSTAMP(st);
 #ifndef FIB_DIAG_NO_BARRIER                 // (diagnostic builds of tools/ubench/diag_strip.hip only)
             __syncthreads();
 #endif
 #ifndef FIB_DIAG_NO_RELOAD
-#pragma unroll
-            for (int q = 0; q < R + 2; ++q) {
-                win[q][0] = B[aW + q * LP];
-                win[q][1] = B[aC + q * LP];
-                win[q][2] = B[aE + q * LP];
-            }
+            window(B, win);
 #endif
         }
         FIB_STAMP(3 + st);
@@ -877,8 +948,14 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                                                                 : mt.epoch + (size_t)(need ? ny * g.tiles_x + nx : tile) * MT_EPOCH_STRIDE);
 #endif
             const unsigned done = (unsigned)tick + 1u;
+#if FIB_WAIT_FORM == 2
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + MT_WAIT_TICKS;
+#elif FIB_WAIT_FORM == 1        // the bound in units of 2^17 ticks of 10 ns (1.31 ms), set by the host: a shift, no multiply, no default
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + ((unsigned long long)((unsigned)mt.snap_var >> 8) << MT_WAIT_SHIFT);
+#else
             const unsigned wait_ms = (unsigned)mt.snap_var >> 8;
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (wait_ms ? (unsigned long long)wait_ms * 100000ull : MT_WAIT_TICKS);
+#endif
             for (;;) {
                 const unsigned e = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // one ballot for everything that is not the ordinary case: a tile gave up (lane 8), or the host's word concerns
@@ -904,13 +981,13 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
                         // the give-up word names the launch (its id is never 0): the host replays from the state THAT launch
                         // started from (fibhip.hip, `recover`); launches queued behind it find the word and leave at their first
                         // boundary without writing anything
+#if FIB_GIVEUP_CAS
                         unsigned expected = 0u;
-                        if (__hip_atomic_compare_exchange_strong(mt.err, &expected, mt.ticks_id >> 16, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT))
-                            // ... and tells the host in ITS memory (page-locked, behind the host's own word): a synchronising
-                            // call then reads a word of host memory instead of copying one from the device behind every launch
-                            __hip_atomic_store(mt.snap_flag + MT_HOST_WORD_AT + MT_GIVEUP_WORD, mt.ticks_id >> 16, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_compare_exchange_strong(mt.err, &expected, mt.ticks_id >> 16, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+#else
+                        __hip_atomic_store(mt.err, mt.ticks_id >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                         mt_abort = 1;
                     }
                     break;
@@ -921,7 +998,19 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         FIB_BSTAMP(4);
         __syncthreads();
         FIB_BSTAMP(5);
-        if (mt_abort == 1) return;                                  // whole workgroup: the results of this launch are void
+        if (mt_abort == 1) {                                        // whole workgroup: the results of this launch are void
+            // A tile that leaves because some tile gave up tells the host WHICH launch that was, in the host's own memory (page-
+            // locked, behind the host's word): a synchronising call then reads a word of host memory instead of copying one from
+            // the device behind every launch.  (Here, on the way out, and not where the wait runs out: the 64-bit address of a
+            // system-scope store inside the poll loop cost the Fenton kernel, which sits at its 128 registers, three spills and
+            // 2 % of its speed — same-box A/B against round 3's kernel, profiles/r04_ab_pair_lds.txt.)
+            if (threadIdx.x == 0) {
+                const unsigned who = __hip_atomic_load(mt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (who != 0u)
+                    __hip_atomic_store(mt.snap_flag + MT_HOST_WORD_AT + MT_GIVEUP_WORD, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
         if (mt_abort == 2) {                                        // the caller wants exactly the ticks done so far: write them back
             if (threadIdx.x == 0) __hip_atomic_fetch_add(mt.err + 2 * MT_EPOCH_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -961,38 +1050,36 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         // ---- the whole box's potential into the tile, as after a sub-step — plus the ring (columns 0 and 63 of the
         // tile, rows 0 and CY+1), which the sub-steps never write
         float *B0 = lds[0];
-        const int wib = (gx >= 1 && gx <= g.W - 2) ? (c0 + 1) * LP + lane : NL + 2 * LP + lane;
+        const int wib = (gx >= 1 && gx <= g.W - 2) ? cell_at(c0 + 1, lane) : cell_at(SPARE_ROW, lane);
         {
             const unsigned live = ra_fix < rb_fix ? ((1u << rb_fix) - 1u) & ~((1u << ra_fix) - 1u) : 0u;
             const unsigned m = live & pub;
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if ((m >> r) & 1u) B0[wib + r * LP] = s[r][0];
+                if ((m >> r) & 1u) B0[wib + ro(r)] = s[r][0];
             if (top_r >= 0 || bot_r >= 0) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (r == top_r && ((live >> r) & 1u)) {
-                        B0[wib + (r - 1) * LP] = s[r][0];
-                        if (c0 + r >= 1) B0[wib + (r - 2) * LP] = s[r][0];
+                        B0[wib + ro(r - 1)] = s[r][0];
+                        if (c0 + r >= 1) B0[wib + ro(r - 2)] = s[r][0];
                     }
                     if (r == bot_r && ((live >> r) & 1u)) {
-                        B0[wib + (r + 1) * LP] = s[r][0];
-                        if (c0 + r + 1 < LQ - 2) B0[wib + (r + 2) * LP] = s[r][0];
+                        B0[wib + ro(r + 1)] = s[r][0];
+                        if (c0 + r + 1 < LQ - 2) B0[wib + ro(r + 2)] = s[r][0];
                     }
                 }
             }
-            if (ring_top) B0[(gx >= 1 && gx <= g.W - 2) ? lane : NL + 2 * LP + lane] = ring;
-            if (ring_bot) B0[(gx >= 1 && gx <= g.W - 2) ? (CY + 1) * LP + lane : NL + 2 * LP + lane] = ring;
+            // (tile rows 0 and CY + 1; in the paired image an even row sits at its word's first dword, an odd one at the second)
+            constexpr int RING_BOT = PAIR ? ((CY + 1) >> 1) * 128 + ((CY + 1) & 1) : (CY + 1) * LP;
+            const int col = PAIR ? 2 * lane : lane, nobody = cell_at(SPARE_ROW, lane);
+            if (ring_top) B0[(gx >= 1 && gx <= g.W - 2) ? col : nobody] = ring;
+            if (ring_bot) B0[(gx >= 1 && gx <= g.W - 2) ? RING_BOT + col : nobody] = ring;
         }
         FIB_BSTAMP(7);
         __syncthreads();
         FIB_BSTAMP(8);
-#pragma unroll
-        for (int q = 0; q < R + 2; ++q) {
-            win[q][0] = B0[aW + q * LP];
-            win[q][1] = B0[aC + q * LP];
-            win[q][2] = B0[aE + q * LP];
-        }
+        window(B0, win);
         FIB_BSTAMP_WAIT();
         FIB_BSTAMP(9);
     }
@@ -1022,6 +1109,18 @@ template <class M, class P, int MODE, int K, int TX, int TY, int R, bool PHASE>
 __global__ void __launch_bounds__(64 * ((TY + 2 * (K - 1) + R - 1) / R))
 strip_mt_kernel(Geo g, PtrTab<M::NVAR> pt, PhaseTab ph, typename M::Consts k, int sub0, MtArgs mt)
 {
+#ifndef FIB_MT_FULL_GEO
+    // The host launches this kernel on whole single-device grids only (fibhip.hip mt_eligible: planar slab, no ghost rows, one band
+    // of rows): say so, and seven of Geo's twelve scalars are constants or copies instead of live scalar registers — the kernel
+    // spills scalar registers into vector lanes as it is, and sits at its 128 vector registers.
+    g.pitch = g.W;
+    g.Hg = g.H;
+    g.row_off = 0;
+    g.r0 = 0;
+    g.r1 = g.H;
+    g.rb0 = g.rb1 = 0;
+    g.ty_a = 0x7fffffff;
+#endif
     strip_body<M, P, MODE, K, TX, TY, R, PHASE, true>(g, pt, ph, k, sub0, mt);
 }
 

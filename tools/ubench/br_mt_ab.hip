@@ -61,7 +61,7 @@ int main(int argc, char **argv)
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> us;
     for (int rep = 0; rep < reps + 5; ++rep) {
-        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, 0};
+        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, (int)(1526u << 8)};
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((strip_mt_kernel<BeelerReuter, POLICY, 1, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
         hipEventRecord(e1, 0);

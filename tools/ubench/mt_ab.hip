@@ -15,7 +15,16 @@ using namespace fib;
 int main(int argc, char **argv)
 {
     const int T = argc > 1 ? atoi(argv[1]) : 32, reps = argc > 2 ? atoi(argv[2]) : 30;
-    constexpr int K = 10, TX = 44, TY = 25, R = 3, H = 512, W = 512;
+#ifndef SUB0_ARG
+#define SUB0_ARG 0
+#endif
+#ifndef TILE_TY
+#define TILE_TY 25
+#endif
+#ifndef STRIP_R
+#define STRIP_R 3
+#endif
+    constexpr int K = 10, TX = 44, TY = TILE_TY, R = STRIP_R, H = 512, W = 512;
     const size_t n = (size_t)H * W;
     float *buf, *xb;
     unsigned *ep;
@@ -44,12 +53,12 @@ int main(int argc, char **argv)
     std::vector<float> us;
     for (int rep = 0; rep < reps + 5; ++rep) {
 #ifdef NEW_ARGS
-        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, 0};
+        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, (int)(1526u << 8)};
 #else
         MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, T, nullptr, nullptr, 0, 0};
 #endif
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((strip_mt_kernel<Fenton, POLICY, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
+        hipLaunchKernelGGL((strip_mt_kernel<Fenton, POLICY, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, SUB0_ARG, mt);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;

@@ -42,7 +42,7 @@ int main(int argc, char **argv)
     memset(hostw, 0, (MT_HOST_WORD_AT + 16) * sizeof(unsigned));
     hipHostGetDevicePointer((void **)&hostw_dev, hostw, 0);
     for (int rep = 0; rep < 5; ++rep) {
-        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, 0};
+        MtArgs mt{xb, ep, ep + 1024 * 64, epoch0, (unsigned)T | ((unsigned)rep + 1u) << 16, nullptr, hostw_dev, 0, (int)(1526u << 8)};
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((strip_mt_kernel<Fenton, Fast, 0, K, TX, TY, R, true>), dim3(grid), dim3(64 * NW), 0, 0, g, pt, ph, k, 0, mt);
         hipEventRecord(e1, 0);
@@ -75,6 +75,42 @@ int main(int argc, char **argv)
         printf("wave %-3d", w);
         for (int q = 0; q < 9; ++q) printf(" %12.0f", acc[q] / cnt);
         printf(" %10.0f | %8.0f\n", tot / cnt, steps / cnt);
+    }
+    // round 4: the sub-steps of the last tick, per wave — cycles from the end of the previous sub-step (barrier passed, window
+    // read) to the arrival at this sub-step's barrier (arithmetic + LDS write: "work") and from there to the end of the sub-step
+    // (barrier wait + window read: "wait").  The last sub-step has no barrier.
+    std::vector<unsigned long long> ws(4096 * 16);
+    hipMemcpyFromSymbol(ws.data(), HIP_SYMBOL(fib_wstamps), ws.size() * 8);
+    printf("\nsub-steps of the last tick: work / wait cycles per wave (mean over the tiles)\n%-8s", "wave");
+    for (int st = 0; st < K; ++st) printf("   step %d      ", st);
+    printf("  sum work  sum wait\n");
+    for (int w = 0; w < NW; ++w) {
+        double work[K] = {0}, wait[K] = {0};
+        int cnt = 0;
+        for (int b = 0; b < grid; ++b) {
+            const int tile = (b & 7) * ((g.ntiles + 7) >> 3) + (b >> 3);
+            if (tile >= g.ntiles) continue;
+            const size_t at = (size_t)((b * 16 + w) % 4096) * 16;
+            const unsigned long long *s = &bs[at], *t = &st[at], *u = &ws[at];
+            for (int q = 0; q < K; ++q) {
+                const unsigned long long begin = q == 0 ? s[9] : t[2 + q];
+                if (q + 1 < K) {
+                    work[q] += (double)(u[q] - begin);
+                    wait[q] += (double)(t[3 + q] - u[q]);
+                } else {
+                    work[q] += (double)(t[3 + q] - begin);
+                }
+            }
+            ++cnt;
+        }
+        double sw = 0, sa = 0;
+        printf("wave %-3d", w);
+        for (int q = 0; q < K; ++q) {
+            printf(" %6.0f/%-6.0f", work[q] / cnt, wait[q] / cnt);
+            sw += work[q] / cnt;
+            sa += wait[q] / cnt;
+        }
+        printf(" %9.0f %9.0f\n", sw, sa);
     }
     return 0;
 }
