@@ -546,7 +546,10 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // Beeler-Reuter's two-row strips: 15.4 -> 15.1 us per tick.  Three-row strips would need two copies of the tile program (a
     // window starts on an even row in every other wave only): built and measured — the registers it costs the Fenton kernel, which
     // sits at its 128, outweigh the LDS cycles (12.3 -> 13.0 us per tick; four-row strips with the paired image: 13.8).
-    constexpr bool PAIR = (R % 2 == 0);
+    // (only where ONE workgroup has the compute unit to itself: with several resident, as on grids beyond 704^2, another workgroup
+    // computes while this one reloads its windows, and the opaque addresses of the separate ds_read_b64 only cost — Beeler-Reuter
+    // 2048^2 with the paired image in strip_kernel: 180.9 -> 184.5 us per tick)
+    constexpr bool PAIR = MT && (R % 2 == 0);
     constexpr int SPARE = PAIR ? R + 6 : R + 4;
     __shared__ __attribute__((aligned(16))) float lds[2][NL + SPARE * 64];   // (+ spare rows: see `wi`)
     __shared__ int mt_abort;
