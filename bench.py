@@ -876,6 +876,42 @@ def bench_ranks(args):
             leg('rows1_leg', lambda: side_leg(a, H, local, rank, world, 20, 3, 4,
                                               "%s %dx%d over %d GPUs, halo scheme 'rows1' (one ghost row of the potential, exchanged after "
                                               "every sub-step, interior on a second stream)" % (args.model, H, args.size, world)))
+        # (d) LAST, because it is the one path no box has exercised between two devices: the library-issued exchange (grouped
+        # ncclSend/ncclRecv on the compute stream, FIBTF_HALO=direct) on the headline's grid — one MI355X talking to itself ran a
+        # configs[3] block 10 % faster through it than through torch's batch_isend_irecv (profiles/r04_exchange_tick_cost.txt).
+        # Its state after the timed ticks is compared bit for bit with a fresh run of the same ticks through the default transport.
+        if os.environ.get('FIBTF_HALO', 'torch') != 'direct' and getattr(args, 'halo', None) != 'rows1':
+            def library_leg():
+                a = copy.copy(base)
+                a.size, a.halo, a.halo_ticks = args.size, getattr(args, 'halo', None), args.halo_ticks
+                os.environ['FIBTF_HALO'] = 'direct'
+                try:
+                    r2 = sharded_run(a, H, local, args.steps, 3, 2 * halo_ticks, min(args.warmup, 8))
+                finally:
+                    os.environ.pop('FIBTF_HALO', None)
+                m2, st2 = r2['m'], r2['st']
+                nticks = r2['setup_ticks'] + min(args.warmup, 8) + 3 * args.steps    # what sharded_run has advanced
+                got = st2.get_state(-1)
+                used = getattr(st2, 'halo_path', 'none')
+                st2.sync()
+                st2.close()
+                m3, (loc3, amp3, s2_ms3) = make_model(a, height=H, device=local)       # the same ticks (and S2) through the default transport
+                m3.define()
+                m3.add_pace_op('s2', loc3, amp3)
+                driver_loop(m3, m3._stepper, m3.millisecond_to_step(s2_ms3), a.model == 'court')(nticks)
+                want = m3._stepper.get_state(-1)
+                m3._stepper.sync()
+                m3._stepper.close()
+                if rank != 0:
+                    return None
+                return {'config': 'the headline\'s grid with the halo exchange issued by the library itself', 'value': round(r2['value'], 1),
+                        'unit': 'Mcell-steps/s', 'n_gpus': world, 'ms_per_step': round(r2['wall'] * 1000.0 / args.steps, 6),
+                        'steps': args.steps, 'wall_ms_per_region': [round(w * 1e3, 4) for w in r2['walls']],
+                        'halo_transport': used, 'halo_wait_s_max_rank': round(r2['halo_wait'], 4),
+                        'equals_default_transport_bitwise': bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))),
+                        'ticks_compared': nticks,
+                        'predicted': predicted_figure(args.size, world, 'ghost', 'library') if args.model == 'fenton' and not args.exact else None}
+            leg('library_transport_leg', library_leg)
         legs_state['current'] = 'teardown'
 
     # orderly teardown: every rank has drained its stream and released the library's communicator before anyone leaves

@@ -190,6 +190,10 @@ def test_bench_side_legs_on_the_headline_grid(gpu_lib):
     ns = line['north_star_512']
     assert ns['value'] > 1000 and ns['n_gpus'] == 2 and ns['predicted']['value'] > 0 and ns['rank0_kernels_us_per_tick'] > 0, ns
     assert line['rows1_leg']['value'] > 100 and line['rows1_leg']['predicted']['value'] > 0, line['rows1_leg']
+    # (gloo ranks cannot take the library's own RCCL exchange: the leg runs on the staged transport and says so; its bitwise
+    # comparison with a fresh run of the same ticks holds all the same)
+    lib = line['library_transport_leg']
+    assert lib['value'] > 100 and lib['equals_default_transport_bitwise'] is True and 'host-staged' in lib['halo_transport'], lib
     assert line['single_device_same_grid']['value'] > 1000 and line['scaling_efficiency']['predicted_efficiency'] > 0
     # the headline was written out before the side legs started
     assert 'headline before the side legs' in r.stderr

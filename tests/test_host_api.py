@@ -177,10 +177,13 @@ def test_bench_multi_gpu_line_schema():
     import bench
     src = open(os.path.join(ROOT, 'bench.py')).read()
     for key in ("'sharded_equals_single'", "'north_star_512'", "'rows1_leg'", "'scaling_efficiency'", "'single_device_same_grid'",
-                "'equal_bitwise'", "'max_abs_diff'", "'predicted'", "'side_legs_timed_out'", 'FIBTF_HEADLINE_FILE'):
+                "'equal_bitwise'", "'max_abs_diff'", "'predicted'", "'side_legs_timed_out'", 'FIBTF_HEADLINE_FILE',
+                "'library_transport_leg'", "'equals_default_transport_bitwise'"):
         assert key in src, key
     assert src.index('emit_early()') < src.index("leg('sharded_equals_single'")      # the headline is out before any side leg
     assert src.index("leg('sharded_equals_single'") < src.index('dist.destroy_process_group()')
+    # the leg that runs a transport no box has exercised between two devices comes LAST
+    assert src.index("leg('rows1_leg'") < src.index("leg('library_transport_leg'") < src.index('dist.destroy_process_group()')
     for world in (2, 4, 8):
         for size in (4096, 512):
             for scheme in ('ghost', 'rows1'):

@@ -18,8 +18,7 @@ from fib_tf_amd import _lib  # noqa: E402
 from fib_tf_amd.sharded import HipEngine, init_from_env  # noqa: E402
 
 init_from_env()
-W, rows = 512, 512
-for g in (10, 40):
+for W, rows, g in ((512, 512, 10), (512, 512, 40), (4096, 512, 40)):      # the last one: a rank's block of BASELINE configs[3] on 8 GPUs
     H = rows + 2 * g
     eng = HipEngine(_lib.FENTON4V, H, W, 0.1, 1.5, _lib.FAST, 10, 4 * rows, rows, g, g, 0)
     rng = np.random.default_rng(0)
@@ -34,7 +33,14 @@ for g in (10, 40):
         for _ in range(cycle - 1):
             eng.step(1)                                    # mid-cycle ticks: no exchange
         eng.step_edges()
-        if direct:
+        if direct == 2:                                    # torch transport, the interior launched BEFORE the messages are posted
+            slab = eng.slabs[eng.next_buf(0)[0]]
+            eng.step_interior()
+            ops = [dist.P2POp(dist.isend, slab[g:2 * g], 0), dist.P2POp(dist.irecv, slab[:g], 0),
+                   dist.P2POp(dist.isend, slab[b - g:b], 0), dist.P2POp(dist.irecv, slab[b:], 0)]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        elif direct:
             eng.comm_exchange(0, 0)
             eng.step_interior()
         else:
@@ -48,7 +54,7 @@ for g in (10, 40):
         eng.step_commit()
 
     with eng.stream_ctx():
-        for direct in (False, True):
+        for direct in (False, 2, True):
             for _ in range(20):
                 tick(direct)
             torch.cuda.synchronize()
@@ -59,8 +65,8 @@ for g in (10, 40):
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            print('ghost %2d rows (%d-tick cycle), %-28s host %6.1f us per cycle (enqueue), %6.1f us per cycle drained = %5.1f us per tick'
-                  % (g, cycle, 'library ncclSend/ncclRecv:' if direct else 'torch batch_isend_irecv:', (t1 - t0) / n * 1e6,
+            print('%dx%d block, ghost %2d rows (%d-tick cycle), %-28s host %6.1f us per cycle (enqueue), %6.1f us per cycle drained = %5.1f us per tick'
+                  % (rows, W, g, cycle, {False: 'torch batch_isend_irecv:', 2: 'torch, interior first:', True: 'library ncclSend/ncclRecv:'}[direct], (t1 - t0) / n * 1e6,
                      (t2 - t0) / n * 1e6, (t2 - t0) / n / cycle * 1e6), flush=True)
     eng.st.close()
 dist.destroy_process_group()
