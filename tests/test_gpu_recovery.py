@@ -66,7 +66,7 @@ SCRIPT = [1, 40, 'get', ('x', 10), 'get', ('x', 10), 'get', ('x', 10), 'get', 'p
 
 
 @pytest.mark.parametrize('H,W,variant', [(96, 100, '10,44,25,-3'), (512, 512, None)])
-@pytest.mark.parametrize('nth', [1, 2, 3, 4, 6, 9])
+@pytest.mark.parametrize('nth', [1, 2, 3, 4, 5, 6, 7, 8, 9, 11])
 def test_a_launch_that_gives_up_does_not_cost_the_run(gpu_lib, monkeypatch, H, W, variant, nth):
     """FIBHIP_MT_FAKE_GIVEUP=n: the n-th multi-tick launch of the handle finds the give-up word raised in its name (what its
     tiles would write after waiting out their bound) and leaves without results, like every launch queued behind it.  The
@@ -85,6 +85,50 @@ def test_a_launch_that_gives_up_does_not_cost_the_run(gpu_lib, monkeypatch, H, W
     assert tpl == 1                                       # ... for good
     assert len(warned) == 1 and 'gave up' in str(warned[0].message)
     assert stats['gave_up_recovered'] == 1 and stats['ticks_recomputed_after_give_up'] == fb[1]
+
+
+@pytest.mark.parametrize('nth', [2, 5, 7])
+def test_beeler_reuter_launch_that_gives_up(gpu_lib, monkeypatch, nth):
+    """the same with eight arrays (two 16-byte exchange cells per grid cell, the paired LDS image of two-row strips)"""
+    H, W = 70, 130
+    rng = np.random.default_rng(9)
+    init = np.empty((8, H, W), np.float32)
+    init[0] = rng.uniform(-85, 20, (H, W))
+    init[1] = rng.uniform(1e-7, 1e-5, (H, W))
+    for v in range(2, 8):
+        init[v] = rng.uniform(0.01, 0.99, (H, W))
+
+    def play(env):
+        for k in ('FIBHIP_MT', 'FIBHIP_MT_FAKE_GIVEUP', 'FIBHIP_AHEAD'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv('FIBHIP_VARIANT', '5,54,21,-2')
+        st = gpu_lib.Stepper(gpu_lib.BR, H, W, 0.1, 0.809, flags=gpu_lib.FAST)       # (direct gates: no table to set)
+        st.set_state(-1, init)
+        out = []
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter('always')
+            for op in (1, 40, 'get', ('x', 10), 'get', ('x', 10), 'get', ('x', 10), 'get', 33, 'sync', ('x', 12)):
+                if isinstance(op, int):
+                    st.step(op)
+                elif op == 'get':
+                    out.append(st.get_state(0).copy())
+                elif op == 'sync':
+                    st.sync()
+                else:
+                    for _ in range(op[1]):
+                        st.step(1)
+            out.append(st.get_state(-1))
+        fb, tpl = st.fallbacks(), st.ticks_per_launch()
+        st.close()
+        return out, fb, tpl
+
+    want, fb0, _ = play({'FIBHIP_MT': '0'})
+    got, fb, tpl = play({'FIBHIP_MT_FAKE_GIVEUP': str(nth)})
+    assert fb0 == (0, 0) and fb[0] == 1 and tpl == 1
+    for i, (x, y) in enumerate(zip(got, want)):
+        assert np.array_equal(x, y), 'observation %d differs after the recovery' % i
 
 
 def test_untouched_run_has_no_fallback(gpu_lib, monkeypatch):
