@@ -1318,6 +1318,16 @@ extern "C" int fibhip_get_state_direct(fibhip_t h, int var, float *dst)
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
+            // The frame is the state the launch STARTED from.  If a launch in front of it gave up, that state is void — and the
+            // tiles of that launch have said so in the host's memory before this launch's tiles could raise their words (one
+            // stream: this launch started after that one had ended).  Then nothing of this launch counts: the state is restored
+            // and recomputed (sync_s0 -> recover) and the frame comes the plain way, below.  (Found by the stress run of
+            // tests/test_gpu_recovery.py: 7 of 400 random call sequences returned a frame of a void state.)
+            if (delivered && __atomic_load_n(h->host_word + MT_GIVEUP_WORD, __ATOMIC_ACQUIRE) != 0u) {
+                h->spec_n = 0;
+                SYNC_S0(h);
+                delivered = false;
+            }
             if (delivered) return 0;
         }
     }

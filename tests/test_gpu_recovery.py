@@ -4,6 +4,7 @@ that declares its series gets it launched whole, and nothing runs ahead of a cal
 The reference has none of this (ionic.py:202-204: one synchronous sess.run per tick), so the yardstick is the library's own
 one-launch-per-tick mode (FIBHIP_MT=0): every observation must match it bit for bit."""
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -129,6 +130,75 @@ def test_beeler_reuter_launch_that_gives_up(gpu_lib, monkeypatch, nth):
     assert fb0 == (0, 0) and fb[0] == 1 and tpl == 1
     for i, (x, y) in enumerate(zip(got, want)):
         assert np.array_equal(x, y), 'observation %d differs after the recovery' % i
+
+
+@pytest.mark.parametrize('seed', range(1, 1 + int(os.environ.get('FIBTF_STRESS_SEEDS', '8'))))      # (a few hundred: a stress run)
+def test_give_up_anywhere_in_random_call_sequences(gpu_lib, monkeypatch, seed):
+    """whatever the caller does around the launch that gives up — single ticks, long calls, paces, probes, host writes, read-backs
+    of one array or all, syncs, declared series, a new phase field — every observation equals the one-launch-per-tick run's"""
+    H, W = 83, 120
+    init, phi = _state(H, W, 200 + seed)
+
+    def play(env):
+        for k in ('FIBHIP_MT', 'FIBHIP_MT_FAKE_GIVEUP', 'FIBHIP_AHEAD'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+        rng = np.random.default_rng(seed)
+        st = gpu_lib.Stepper(gpu_lib.FENTON4V, H, W, 0.1, 1.3, flags=gpu_lib.FAST)
+        st.set_phase(phi)
+        st.set_state(-1, init)
+        seen = []
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter('always')
+            for _ in range(120):
+                op = rng.choice(['step1', 'step1', 'step1', 'step1', 'stepn', 'series', 'pace', 'probe', 'get1', 'getall', 'set1', 'sync',
+                                 'expect', 'phase'])
+                if op == 'step1':
+                    st.step(1)
+                elif op == 'stepn':
+                    st.step(int(rng.integers(0, 70)))
+                elif op == 'series':                       # the reference driver's pattern: n ticks, a frame, n ticks, a frame
+                    n = int(rng.integers(2, 12))
+                    for _ in range(3):
+                        for _ in range(n):
+                            st.step(1)
+                        seen.append(st.get_state(0).copy())
+                elif op == 'pace':
+                    r0, c0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+                    st.pace(r0, r0 + 4, c0, c0 + 4, 1.0, 0.0)
+                elif op == 'probe':
+                    seen.append(np.float32(st.probe(int(rng.integers(0, 4)), int(rng.integers(0, H)), int(rng.integers(0, W)))))
+                elif op == 'get1':
+                    seen.append(st.get_state(int(rng.integers(0, 4))).copy())
+                elif op == 'getall':
+                    seen.append(st.get_state(-1))
+                elif op == 'set1':
+                    v = int(rng.integers(1, 4))
+                    st.set_state(v, (st.get_state(v) * np.float32(0.999)).astype(np.float32))
+                elif op == 'sync':
+                    st.sync()
+                elif op == 'expect':
+                    st.expect(int(rng.integers(0, 40)))     # kept or broken, as the following calls happen to fall
+                else:
+                    st.set_phase(phi if rng.integers(0, 2) else None)
+            seen.append(st.get_state(-1))
+        fb, stats = st.fallbacks(), st.launch_stats()
+        st.close()
+        return seen, fb, stats
+
+    want, fb0, _ = play({'FIBHIP_MT': '0'})
+    untouched, fbu, free = play({})                        # (also: how many multi-tick launches this sequence has)
+    assert fb0 == (0, 0) and fbu == (0, 0) and free['mt_launches'] >= 3
+    for i, (x, y) in enumerate(zip(untouched, want)):      # declared series kept and broken, run-ahead, stops: nothing shows
+        assert np.array_equal(x, y), 'observation %d of the untouched run differs' % i
+    nth = 1 + (seed * 7 + int(os.environ.get('FIBTF_STRESS_SALT', '0'))) % max(1, int(free['mt_launches']))
+    got, fb, _ = play({'FIBHIP_MT_FAKE_GIVEUP': str(nth)})
+    assert fb[0] == 1, (nth, fb)
+    assert len(got) == len(want)
+    for i, (x, y) in enumerate(zip(got, want)):
+        assert np.array_equal(x, y), 'observation %d differs (launch %d of %d gave up)' % (i, nth, free['mt_launches'])
 
 
 def test_untouched_run_has_no_fallback(gpu_lib, monkeypatch):
