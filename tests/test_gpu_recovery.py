@@ -136,17 +136,27 @@ def test_beeler_reuter_launch_that_gives_up(gpu_lib, monkeypatch, nth):
 def test_give_up_anywhere_in_random_call_sequences(gpu_lib, monkeypatch, seed):
     """whatever the caller does around the launch that gives up — single ticks, long calls, paces, probes, host writes, read-backs
     of one array or all, syncs, declared series, a new phase field — every observation equals the one-launch-per-tick run's"""
-    H, W = 83, 120
-    init, phi = _state(H, W, 200 + seed)
+    # (stress runs: FIBTF_STRESS_GRID=512 = the benchmark's own tiling, 252 workgroups on 256 compute units; FIBTF_STRESS_MODEL=br)
+    H, W = (83, 120) if not os.environ.get('FIBTF_STRESS_GRID') else (int(os.environ['FIBTF_STRESS_GRID']),) * 2
+    br = os.environ.get('FIBTF_STRESS_MODEL') == 'br'
+    init, phi = _state(H, W, 200 + seed, 8 if br else 4)
+    if br:
+        init[0] = init[0] * 100.0 - 85.0
+        init[1] *= 1e-5
+        init[2:] = init[2:] * 0.98 + 0.01
+    nvar = 8 if br else 4
 
     def play(env):
         for k in ('FIBHIP_MT', 'FIBHIP_MT_FAKE_GIVEUP', 'FIBHIP_AHEAD'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        monkeypatch.setenv('FIBHIP_VARIANT', '10,44,25,-3')
+        if H == 83:
+            monkeypatch.setenv('FIBHIP_VARIANT', '5,54,21,-2' if br else '10,44,25,-3')
+        else:
+            monkeypatch.delenv('FIBHIP_VARIANT', raising=False)
         rng = np.random.default_rng(seed)
-        st = gpu_lib.Stepper(gpu_lib.FENTON4V, H, W, 0.1, 1.3, flags=gpu_lib.FAST)
+        st = gpu_lib.Stepper(gpu_lib.BR if br else gpu_lib.FENTON4V, H, W, 0.1, 0.809 if br else 1.3, flags=gpu_lib.FAST)
         st.set_phase(phi)
         st.set_state(-1, init)
         seen = []
@@ -167,15 +177,15 @@ def test_give_up_anywhere_in_random_call_sequences(gpu_lib, monkeypatch, seed):
                         seen.append(st.get_state(0).copy())
                 elif op == 'pace':
                     r0, c0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
-                    st.pace(r0, r0 + 4, c0, c0 + 4, 1.0, 0.0)
+                    st.pace(r0, r0 + 4, c0, c0 + 4, 10.0 if br else 1.0, -90.0 if br else 0.0)
                 elif op == 'probe':
-                    seen.append(np.float32(st.probe(int(rng.integers(0, 4)), int(rng.integers(0, H)), int(rng.integers(0, W)))))
+                    seen.append(np.float32(st.probe(int(rng.integers(0, nvar)), int(rng.integers(0, H)), int(rng.integers(0, W)))))
                 elif op == 'get1':
-                    seen.append(st.get_state(int(rng.integers(0, 4))).copy())
+                    seen.append(st.get_state(int(rng.integers(0, nvar))).copy())
                 elif op == 'getall':
                     seen.append(st.get_state(-1))
                 elif op == 'set1':
-                    v = int(rng.integers(1, 4))
+                    v = int(rng.integers(2, nvar))
                     st.set_state(v, (st.get_state(v) * np.float32(0.999)).astype(np.float32))
                 elif op == 'sync':
                     st.sync()
