@@ -716,6 +716,9 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
     // (and only where the registers are there and the bookkeeping is a visible share of the sub-step: four-row strips spilled
     // with the second loop — at 16 waves per workgroup the budget is 128 registers — and Beeler-Reuter's eight arrays with ~270
     // instructions per cell ran 1.5-3 % slower with it; both keep one loop)
+#ifndef FIB_PRE_FIRST
+#define FIB_PRE_FIRST 0
+#endif
 #ifndef FIB_WHOLE_NVR
 #define FIB_WHOLE_NVR 12
 #endif
@@ -753,6 +756,35 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
         for (int st = 0; st < K; ++st) {
             float *B = lds[(st & 1) ^ 1];
             float lp[R], cc[R];
+#if FIB_PRE_FIRST
+            // (experiment) the part of the update that needs no neighbour — the whole reaction term — is ISSUED before anything
+            // waits for the window the barrier's other side has just requested from the LDS
+            float dU[R];
+            M::template stepN_pre<P, MODE, R>(s, dU, kk);
+#if FIB_PRE_FIRST >= 2
+            // two statements the compiler keeps in order: the first consumes everything the reaction term produced, the second
+            // "produces" the window — so the wait for the LDS sits between them
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                asm volatile("" ::"v"(dU[r]));
+#pragma unroll
+                for (int v = 1; v < NV; ++v) asm volatile("" ::"v"(s[r][v]));
+            }
+#pragma unroll
+            for (int r = 0; r < R + 2; ++r) asm volatile("" : "+v"(win[r][0]), "+v"(win[r][1]), "+v"(win[r][2]));
+#else
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
+                                  win[r][2], win[r + 2][2], win[r + 1][1]);
+                if (PHASE) l = pc[r].add(l, win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2]);
+                lp[r] = l;
+                cc[r] = win[r + 1][1];
+            }
+            M::template stepN_post<P, MODE, R>(s, dU, cc, lp, kk);
+#else
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float l = lap9<P>(win[r][1], win[r + 2][1], win[r + 1][0], win[r + 1][2], win[r][0], win[r + 2][0],
@@ -767,6 +799,7 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #pragma unroll
                 for (int r = 0; r < R; ++r) M::template step<P, MODE>(s[r], cc[r], lp[r], kk, sub0 + st);
             }
+#endif
             if (st + 1 < K) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) B[wi + ro(r)] = s[r][0];
@@ -776,6 +809,11 @@ static FIB_DEV void strip_body(const Geo &g, const PtrTab<M::NVAR> &pt, const Ph
 #endif
 #ifndef FIB_DIAG_NO_RELOAD
                 window(B, win);
+#endif
+#if FIB_PRE_FIRST == 3
+                // (the state as the reaction term sees it exists only on this side of the barrier and of the window's reads)
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(s[r][0]), "+v"(s[r][1]), "+v"(s[r][2]), "+v"(s[r][3])::"memory");
 #endif
             }
             FIB_STAMP(3 + st);
