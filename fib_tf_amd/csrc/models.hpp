@@ -355,6 +355,21 @@ static FIB_DEV float rush_larsen_c(float g, float ginf, float em1)
 }
 
 #define FC(x) ((float)(x))
+// Fenton, fast policy: bit 0 = U*G(b) as U - U*H(b) (exact: one multiply-add for a Heaviside and a product), bit 1 = the second
+// sigmoid itself instead of one minus its complement.  Two instructions of 52 fewer per cell: the kernels' sub-steps cost what their
+// arithmetic costs.  0 = the forms of rounds 2-3, kept for same-box A/B (tools/r04_l.sh).
+#ifndef FIB_FENTON_FEWER
+#define FIB_FENTON_FEWER 3
+#endif
+// Beeler-Reuter, fast policy (br_step.inc): 1 = every a*b+c of the currents that the reference leaves as two operations as ONE
+// multiply-add and log C as the bare v_log_f32 (C is never subnormal); 2 = constant factors folded into neighbouring multiply-adds.
+// 222 -> 202 instructions per cell; the error along the golden trajectories is the one of the old forms (tools/r04_p.sh).  0 = the
+// forms of rounds 1-3, kept for same-box A/B.  (Measured and NOT taken: the twelve sums by Horner's rule, x as one multiply-add —
+// 13 instructions fewer, but the ascending sums are what the reference computes and its rounding errors are what parity is
+// measured against: 4-10 x the distance from the golden trajectories)
+#ifndef FIB_BR_FEWER
+#define FIB_BR_FEWER 2
+#endif
 // x / (float constant c), through the constant's correctly rounded reciprocal
 #define DC(x, c) P::divc((x), FC(c), 1.0f / FC(c))
 
