@@ -207,6 +207,24 @@ static FIB_DEV float one_plus_tanh_rf(float x)
     return __builtin_fmaf(-2.0f, r, 2.0f);
 }
 
+// Fenton, fewer instructions per cell (the kernels' sub-steps cost what their arithmetic costs).  Fast policy: bit 0 =
+// U*G(b) as U - U*H(b) (exact: one multiply-add for a Heaviside and a product), bit 1 = the second sigmoid itself instead of one minus
+// its complement (52 -> 50 per cell).  Rounding-faithful policy, bit 4: where one factor of a*b + c is 0, 0.5 or 1 (the Heavisides) or
+// exactly 0.5, the product is EXACT and the reference's two roundings are the one rounding of a fused multiply-add — the same bits in
+// one instruction: H*tau_a + x, H*(r_sp - r_sn) + r_sn, x*0.5 - S, and (U - u_0)*G as U - U*H (kernel 18.3 -> 17.3 us per tick).
+// 0 = the forms of rounds 2-3, kept for same-box A/B (tools/r04_l.sh, r04_q.sh).
+#ifndef FIB_FENTON_FEWER
+#define FIB_FENTON_FEWER 19
+#endif
+// Beeler-Reuter, fast policy (br_step.inc): 1 = every a*b+c of the currents that the reference leaves as two operations as ONE
+// multiply-add and log C as the bare v_log_f32 (C is never subnormal); 2 = constant factors folded into neighbouring multiply-adds.
+// 222 -> 202 instructions per cell; the error along the golden trajectories is the one of the old forms (tools/r04_p.sh).  0 = the
+// forms of rounds 1-3, kept for same-box A/B.  (Measured and NOT taken: the twelve sums by Horner's rule, x as one multiply-add —
+// 13 instructions fewer, but the ascending sums are what the reference computes and its rounding errors are what parity is
+// measured against: 4-10 x the distance from the golden trajectories, DESIGN.md 6.)
+#ifndef FIB_BR_FEWER
+#define FIB_BR_FEWER 2
+#endif
 struct Exact {
     // a*b + c: the reference rounds the product and the sum separately
     template <class T, class B, class C>
@@ -230,7 +248,14 @@ struct Exact {
     static FIB_DEV T one_plus_tanh(const T &a) { return vmap(a, [](float x) { return one_plus_tanh_rf(x); }); }
 #endif
     template <class T>
-    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s) { return one_plus_tanh(a) * 0.5f + (-s); }
+    static FIB_DEV T half_one_plus_tanh_minus(const T &a, const T &s)
+    {
+#if FIB_FENTON_FEWER & 16      // (halving is exact: the two roundings of x * 0.5 + (-s) are the one rounding of a fused multiply-add)
+        return vfma(one_plus_tanh(a), 0.5f, -s);
+#else
+        return one_plus_tanh(a) * 0.5f + (-s);
+#endif
+    }
     template <class A, class T>
     static FIB_DEV T div(const A &a, const T &b) { return vzip(a, b, [](float x, float y) { return x / y; }); }
     template <class T> static FIB_DEV T rcp(const T &a) { return vmap(a, [](float x) { return 1.0f / x; }); }
@@ -355,21 +380,6 @@ static FIB_DEV float rush_larsen_c(float g, float ginf, float em1)
 }
 
 #define FC(x) ((float)(x))
-// Fenton, fast policy: bit 0 = U*G(b) as U - U*H(b) (exact: one multiply-add for a Heaviside and a product), bit 1 = the second
-// sigmoid itself instead of one minus its complement.  Two instructions of 52 fewer per cell: the kernels' sub-steps cost what their
-// arithmetic costs.  0 = the forms of rounds 2-3, kept for same-box A/B (tools/r04_l.sh).
-#ifndef FIB_FENTON_FEWER
-#define FIB_FENTON_FEWER 3
-#endif
-// Beeler-Reuter, fast policy (br_step.inc): 1 = every a*b+c of the currents that the reference leaves as two operations as ONE
-// multiply-add and log C as the bare v_log_f32 (C is never subnormal); 2 = constant factors folded into neighbouring multiply-adds.
-// 222 -> 202 instructions per cell; the error along the golden trajectories is the one of the old forms (tools/r04_p.sh).  0 = the
-// forms of rounds 1-3, kept for same-box A/B.  (Measured and NOT taken: the twelve sums by Horner's rule, x as one multiply-add —
-// 13 instructions fewer, but the ascending sums are what the reference computes and its rounding errors are what parity is
-// measured against: 4-10 x the distance from the golden trajectories, DESIGN.md 6.)
-#ifndef FIB_BR_FEWER
-#define FIB_BR_FEWER 2
-#endif
 // x / (float constant c), through the constant's correctly rounded reciprocal
 #define DC(x, c) P::divc((x), FC(c), 1.0f / FC(c))
 
