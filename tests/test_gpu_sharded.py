@@ -199,6 +199,30 @@ def test_bench_side_legs_on_the_headline_grid(gpu_lib):
     assert 'headline before the side legs' in r.stderr
 
 
+def test_bench_under_the_drivers_launcher(gpu_lib):
+    """the driver's own way of starting N ranks — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — rehearsed with 2 gloo ranks sharing the one GPU: one JSON
+    line on stdout (rank 0's), side legs included, exit code 0 (no rank leaves early, nothing for the elastic agent to flag)"""
+    import json
+    import subprocess
+    from test_sharded_cpu import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', FIBTF_ONE_DEVICE='1', FIBTF_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '4',
+           '--setup', '8', '--no-cpu']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 8 and line['warmup'] == 4 and line['value'] > 1000
+    assert line['sharded_equals_single'].get('equal_bitwise') is True, line['sharded_equals_single']
+    for key in ('north_star_512', 'rows1_leg', 'library_transport_leg', 'single_device_same_grid', 'scaling_efficiency'):
+        assert key in line, key
+
+
 def test_direct_rccl_exchange_self(gpu_lib, tmp_path):
     """the opt-in direct halo path (FIBTF_HALO=direct): RCCL bound with dlopen, communicator created by the library,
     one grouped ncclSend/ncclRecv exchange on the handle's stream — with a one-rank communicator (tests/rccl_direct_worker.py)"""
