@@ -1,4 +1,5 @@
 #!/bin/bash
+# (levels 3 and 4 were measured and removed again — 4-10 x further from the golden trajectories, profiles/r04_fewer_instructions.txt — the tree has 0 .. 2)
 # round 4, run N: FIB_BR_FEWER=4 (x as one multiply-add, iK1's first quotient with one instruction fewer) against 3 and 0
 mkdir -p gpurun_out/r04
 cd tools/ubench

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, run O: Fenton fast, FIB_FENTON_FEWER bits 2 (the outward current's chain negated in its constants: a literal instead of a
-# scalar register in its last multiply-add) and 3 (the excitation test on the difference a = U - u_c instead of on U): 3 = shipped so far
+# scalar register in its last multiply-add) and 3 (the excitation test on the difference a = U - u_c instead of on U): 3 = shipped so far.
+# (Both forms were built from a scratch copy of csrc/ and did not gain: they are NOT in the tree — profiles/r04_fewer_instructions.txt has the numbers.)
 mkdir -p gpurun_out/r04
 cd tools/ubench
 for round in 1 2 3 4; do
