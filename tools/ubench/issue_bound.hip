@@ -23,7 +23,13 @@ typedef BeelerReuter MODEL;
 constexpr int MODE_ = 1, R_ = 2;
 #else
 typedef Fenton MODEL;
-constexpr int MODE_ = 0, R_ = 3;
+#ifndef RROWS
+#define RROWS 3
+#endif
+constexpr int MODE_ = 0, R_ = RROWS;
+#endif
+#ifndef PAD_KB                  // LDS per workgroup: 96 KB = one workgroup per compute unit, 40 KB = two (waves per SIMD doubled)
+#define PAD_KB 96
 #endif
 #ifndef NWAVES
 #define NWAVES 15
@@ -33,7 +39,7 @@ template <class M, class P, int MODE, int R, int NW>
 __global__ __launch_bounds__(64 * NW) void issue_kernel(float *buf, const typename M::Consts k, int n_iter, unsigned long long *cyc)
 {
     constexpr int NV = M::NVAR;
-    __shared__ float pad[24 * 1024];                                // 96 KB: one workgroup per compute unit
+    __shared__ float pad[PAD_KB * 256];                             // (PAD_KB: how many workgroups share a compute unit)
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = (size_t)gridDim.x * blockDim.x;
     if (n_iter < 0) pad[threadIdx.x] = buf[tid];                    // (never: keeps the array)
