@@ -302,8 +302,16 @@ struct Fast {
 #ifdef FIB_DIAG_NOTRANS                     // (diagnostic builds only: what do the transcendental instructions cost?)
         return x * 0.001f + 0.5f;
 #else
+#if defined(FIB_DIAG_NOEXP)                 // (diagnostic builds: the two transcendentals priced separately)
+        const T e = x * 0.001f;
+#else
         const T e = vmap(x, [](float y) { return __builtin_amdgcn_exp2f(y); });
+#endif
+#if defined(FIB_DIAG_NORCP)
+        return (e + 1.0f) * 0.37f;
+#else
         return vmap(e + 1.0f, [](float y) { return __builtin_amdgcn_rcpf(y); });
+#endif
 #endif
     }
     template <class T>
