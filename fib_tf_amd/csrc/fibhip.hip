@@ -50,6 +50,7 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // kernel variants
 // ------------------------------------------------------------------------------------------
 constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
+constexpr int MT_DONE_WORD = 12;          // words behind the host's word (kernels.hpp MT_HOST_WORD_AT): written by the STREAM, see wait_s0
 constexpr int AT_MT_TICKS = 8;           // autotune times a multi-tick candidate as one launch of this many ticks
 static const char *const MT_DEAD_MSG =
     "a multi-tick launch gave up (a tile waited its full bound for a neighbouring tile: were all workgroups resident? is another "
@@ -476,6 +477,8 @@ struct fibhip_ctx {
     bool ahead_ok;                  // FIBHIP_AHEAD != 0
     unsigned spec_id;               // ... of the launch that ran ahead
     unsigned *host_word;            // page-locked (behind snap_flags), read by tile 0 over PCIe: {launch id << 16 | n}, see flush()
+    unsigned done_seq;              // wait_s0: the value the stream writes into host_word[MT_DONE_WORD] when it has got that far
+    bool no_stream_write;
     unsigned *snap_flags_dev;       // device address of snap_flags
     unsigned mt_ids;                // launch ids cycle through 1 .. mt_ids
     unsigned mt_seq;                // id of the last multi-tick launch (the host's word names the launch it is meant for)
@@ -928,6 +931,11 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
         h->mt_ids = (e && atoi(e) >= 2 && atoi(e) <= 65535) ? (unsigned)atoi(e) : 65535u;
     }
     h->host_word = h->snap_flags_dev = nullptr;
+    h->done_seq = 0;
+    {
+        const char *e = getenv("FIBHIP_STREAM_WRITE");             // 0: notice the end of the stream's work through hipStreamQuery, as before
+        h->no_stream_write = e && atoi(e) == 0;
+    }
     h->snap_flags = nullptr;
     h->snap_seq = 0;
     {
@@ -1058,6 +1066,28 @@ static hipError_t wait_stream(hipStream_t s)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(lim)) return hipStreamSynchronize(s);
     }
 }
+// The end of everything enqueued on the handle's stream, noticed through a word of page-locked host memory that the stream itself
+// writes when it gets there (hipStreamWriteValue32 behind the work) instead of through hipStreamQuery: the host spins on its own
+// memory, and knows 3 us sooner (tools/ubench/notice.hip: launch call -> notice, minus the kernel: 8.5 us by hipStreamQuery spin,
+// 7.6 by hipStreamSynchronize, 5.3 this way) — 1 % of a 20-tick region of the benchmark, and of every read-back of a driver loop.
+static hipError_t wait_s0(fibhip_ctx *h)
+{
+    const long lim = spin_us();
+    if (lim <= 0 || !h->host_word || h->no_stream_write) return wait_stream(h->s0);
+    const unsigned seq = ++h->done_seq;
+    volatile unsigned *w = h->host_word + MT_DONE_WORD;
+    if (hipStreamWriteValue32(h->s0, h->snap_flags_dev + MT_HOST_WORD_AT + MT_DONE_WORD, seq, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        h->no_stream_write = true;                     // (a runtime or a stream that cannot: the old way from now on)
+        return wait_stream(h->s0);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(lim)) return hipStreamSynchronize(h->s0);
+    }
+    return hipSuccess;
+}
 static hipError_t wait_event(hipEvent_t ev)
 {
     const long lim = spin_us();
@@ -1112,7 +1142,7 @@ static int recover(fibhip_ctx *h, unsigned id)
 
 static int sync_s0(fibhip_ctx *h)
 {
-    HIPCHK(wait_stream(h->s0));
+    HIPCHK(wait_s0(h));
     if (h->mt_inflight && h->epochs) {
         // the tile that gave up first has written its launch's id into HOST memory (page-locked, behind the host's own word):
         // nothing is copied from the device behind every launch (a 4-byte device-to-host copy at the end of every
