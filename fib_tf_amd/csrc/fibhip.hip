@@ -50,7 +50,6 @@ extern "C" const char *fibhip_last_error(void) { return g_err; }
 // kernel variants
 // ------------------------------------------------------------------------------------------
 constexpr int MT_MAX_TICKS = 32;          // default bound on the ticks of one launch (0.4 ms of Fenton 512x512)
-constexpr int MT_DONE_WORD = 12;          // words behind the host's word (kernels.hpp MT_HOST_WORD_AT): written by the STREAM, see wait_s0
 constexpr int AT_MT_TICKS = 8;           // autotune times a multi-tick candidate as one launch of this many ticks
 static const char *const MT_DEAD_MSG =
     "a multi-tick launch gave up (a tile waited its full bound for a neighbouring tile: were all workgroups resident? is another "
@@ -477,7 +476,8 @@ struct fibhip_ctx {
     bool ahead_ok;                  // FIBHIP_AHEAD != 0
     unsigned spec_id;               // ... of the launch that ran ahead
     unsigned *host_word;            // page-locked (behind snap_flags), read by tile 0 over PCIe: {launch id << 16 | n}, see flush()
-    unsigned done_seq;              // wait_s0: the value the stream writes into host_word[MT_DONE_WORD] when it has got that far
+    unsigned *done_word, *done_word_dev;    // wait_s0: a word of page-locked memory of its own (host / device address) ...
+    unsigned done_seq;              // ... and the value the stream writes into it when it has got that far
     bool no_stream_write;
     unsigned *snap_flags_dev;       // device address of snap_flags
     unsigned mt_ids;                // launch ids cycle through 1 .. mt_ids
@@ -932,6 +932,7 @@ static int create_impl(const fibhip_desc *desc, fibhip_ctx *&h)
     }
     h->host_word = h->snap_flags_dev = nullptr;
     h->done_seq = 0;
+    h->done_word = h->done_word_dev = nullptr;
     {
         const char *e = getenv("FIBHIP_STREAM_WRITE");             // 0: notice the end of the stream's work through hipStreamQuery, as before
         h->no_stream_write = e && atoi(e) == 0;
@@ -1029,6 +1030,7 @@ extern "C" int fibhip_destroy(fibhip_t h)
     }
     mt_forget(h);
     if (h->snap_flags) hipHostFree(h->snap_flags);
+    if (h->done_word) hipHostFree(h->done_word);
     if (h->probe_host) hipHostFree(h->probe_host);
     if (h->stage) hipHostFree(h->stage);
     if (h->ev_spec) hipEventDestroy(h->ev_spec);
@@ -1066,17 +1068,29 @@ static hipError_t wait_stream(hipStream_t s)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(lim)) return hipStreamSynchronize(s);
     }
 }
-// The end of everything enqueued on the handle's stream, noticed through a word of page-locked host memory that the stream itself
+// The end of everything enqueued on the handle's stream (any handle: single device or shard, whatever the launch plan), noticed
+// through a word of page-locked host memory that the stream itself
 // writes when it gets there (hipStreamWriteValue32 behind the work) instead of through hipStreamQuery: the host spins on its own
 // memory, and knows 3 us sooner (tools/ubench/notice.hip: launch call -> notice, minus the kernel: 8.5 us by hipStreamQuery spin,
 // 7.6 by hipStreamSynchronize, 5.3 this way) — 1 % of a 20-tick region of the benchmark, and of every read-back of a driver loop.
 static hipError_t wait_s0(fibhip_ctx *h)
 {
     const long lim = spin_us();
-    if (lim <= 0 || !h->host_word || h->no_stream_write) return wait_stream(h->s0);
+    if (lim <= 0 || h->no_stream_write) return wait_stream(h->s0);
+    if (!h->done_word) {                               // (first use: 64 bytes of page-locked memory per handle)
+        if (hipHostMalloc((void **)&h->done_word, 64, hipHostMallocDefault) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&h->done_word_dev, h->done_word, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->done_word) hipHostFree(h->done_word);
+            h->done_word = nullptr;
+            h->no_stream_write = true;
+            return wait_stream(h->s0);
+        }
+        *h->done_word = 0u;
+    }
     const unsigned seq = ++h->done_seq;
-    volatile unsigned *w = h->host_word + MT_DONE_WORD;
-    if (hipStreamWriteValue32(h->s0, h->snap_flags_dev + MT_HOST_WORD_AT + MT_DONE_WORD, seq, 0) != hipSuccess) {
+    volatile unsigned *w = h->done_word;
+    if (hipStreamWriteValue32(h->s0, h->done_word_dev, seq, 0) != hipSuccess) {
         (void)hipGetLastError();
         h->no_stream_write = true;                     // (a runtime or a stream that cannot: the old way from now on)
         return wait_stream(h->s0);
